@@ -1,0 +1,139 @@
+/*
+ * probunet.h — C ABI of libprobunet.so: MI355X (gfx950) engine for the Probabilistic U-Net ELBO
+ * forward+backward and prior-sampling hot path.
+ *
+ * The reference (MaryamAlipourH/prob-unet-climate-downscaling) has no FFI: its seam is the Python class
+ * ProbabilisticUNet (src/prob_unet.py:140-267). Each entry point below names the reference interface it
+ * replaces; the Python shim prob-unet-climate-downscaling_amd/prob_unet.py binds them with ctypes
+ * (see INTEGRATION.md for the binding a maintainer of the reference would add).
+ *
+ * Conventions
+ *   - return 0 on success, negative pu_status on failure; never throws; pu_last_error(ctx) gives a message.
+ *   - every pointer is a raw DEVICE pointer owned by the caller unless stated; the library never frees them.
+ *   - user-facing tensors are fp32, NCHW, contiguous (what the reference passes, train_prob_unet_model.py:123-125).
+ *   - all work is enqueued on the hipStream_t passed in (void* here so that the header needs no HIP include);
+ *     no hidden device synchronisation except where stated ("syncs").
+ *   - one pu_ctx per (process, device); a ctx is not thread-safe.
+ *   - activations inside the engine are NHWC in the ctx compute dtype; parameters always have an fp32 master copy
+ *     in the caller's flat buffer (reference state_dict order, see pu_param_table).
+ */
+#ifndef PROBUNET_H
+#define PROBUNET_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pu_ctx pu_ctx;
+
+typedef enum {
+  PU_OK = 0,
+  PU_ERR_INVALID = -1,      /* bad argument / unsupported configuration */
+  PU_ERR_HIP = -2,          /* a HIP runtime call failed */
+  PU_ERR_STATE = -3,        /* call order violated (e.g. backward without forward, params not bound) */
+  PU_ERR_NOMEM = -4
+} pu_status;
+
+typedef enum { PU_F32 = 0, PU_F16 = 1, PU_BF16 = 2 } pu_dtype;
+typedef enum { PU_PRIOR = 0, PU_POSTERIOR = 1 } pu_net;
+typedef enum { PU_RECON_AFCRPS = 0, PU_RECON_L1 = 1 } pu_recon;
+
+#define PU_MAX_LEVELS 8
+
+/* ProbabilisticUNet.__init__ arguments (prob_unet.py:146) + engine sizing. */
+typedef struct {
+  int32_t input_channels;              /* x planes */
+  int32_t num_classes;                 /* target / output planes */
+  int32_t latent_dim;
+  int32_t depth;                       /* len(num_filters) == len(channel_mult) */
+  int32_t num_filters[PU_MAX_LEVELS];  /* prior/posterior encoder widths; num_filters[0] = U-Net feature planes */
+  int32_t model_channels;
+  int32_t channel_mult[PU_MAX_LEVELS];
+  int32_t H, W;                        /* field size; must be divisible by 2^(depth-1), deepest level >= 8x8 */
+  int32_t max_batch;                   /* activations are planned for this many field pairs */
+  int32_t max_members;                 /* max M (ELBO ensemble) / max n (samples per input in pu_sample) */
+  int32_t dtype;                       /* pu_dtype: arithmetic type of activations and MFMA operands */
+  float   dropout_p;                   /* UNetBlock dropout (networks.py:239), applied when train != 0 */
+} pu_config;
+
+/* One state_dict entry of the reference (prob_unet.py / networks.py registration order). */
+typedef struct {
+  char    name[96];                    /* e.g. "unet.enc.128x128_block0.conv0.weight" */
+  int32_t ndim;
+  int32_t shape[4];
+  int64_t offset;                      /* element offset into the flat fp32 buffers; -1 for buffers (resample_filter) */
+  int32_t is_buffer;                   /* 1 = registered buffer (constant 0.25), not trained */
+} pu_param_desc;
+
+/* Scalars written by pu_elbo_fwd_bwd (device array of PU_NUM_SCALARS floats). */
+enum { PU_S_TOTAL = 0, PU_S_RECON = 1, PU_S_KL_MEAN = 2, PU_S_KL2_MEAN = 3, PU_NUM_SCALARS = 8 };
+
+/* ---- lifetime (replaces ProbabilisticUNet.__init__, prob_unet.py:146-189) ------------------------------- */
+int pu_create(const pu_config* cfg, int device, pu_ctx** out);
+int pu_destroy(pu_ctx* ctx);
+const char* pu_last_error(pu_ctx* ctx);            /* ctx may be NULL: last creation error */
+int pu_abi_version(void);
+
+/* ---- parameters (replaces nn.Module.state_dict()/parameters()) --------------------------- */
+int pu_param_table(pu_ctx* ctx, const pu_param_desc** out, int* n);
+int64_t pu_param_count(pu_ctx* ctx);               /* number of fp32 elements in the flat buffers */
+/* flat_params / flat_grads: device fp32 arrays of pu_param_count elements. Gradients are WRITTEN (not
+ * accumulated) by pu_elbo_fwd_bwd and the *_bwd calls that state so. */
+int pu_bind_params(pu_ctx* ctx, float* flat_params, float* flat_grads);
+/* Tell the engine the fp32 master weights changed (optimizer step / load_state_dict): low-precision packed
+ * copies are rebuilt on the next call. */
+int pu_params_changed(pu_ctx* ctx);
+
+/* ---- sub-modules (replace model.unet(x), model.prior(x)/model.posterior(x,y), model.fcomb(f,z)) --------- */
+/* networks.py:299-333. x [B,Cin,H,W] -> feat [B,F0,H,W]. train!=0 enables dropout with drop_seed. */
+int pu_unet_fwd(pu_ctx*, const float* x, float* feat, int B, int train, uint64_t drop_seed, void* stream);
+/* backward of the LAST pu_unet_fwd: dfeat [B,F0,H,W] -> parameter grads ADDED into flat_grads (x needs no grad). */
+int pu_unet_bwd(pu_ctx*, const float* dfeat, void* stream);
+/* prob_unet.py:56-85. -> mu [B,L], log_sigma [B,L] (sigma = exp(log_sigma) + 1e-7 is the caller's). */
+int pu_gauss_fwd(pu_ctx*, int which, const float* x, const float* target_or_null, float* mu, float* log_sigma,
+                 int B, void* stream);
+int pu_gauss_bwd(pu_ctx*, int which, const float* dmu, const float* dlog_sigma, void* stream);
+/* prob_unet.py:120-138. feat [B,F0,H,W] with batch stride feat_bstride elements (0 => one feature map broadcast
+ * to all B, the expand() pattern of latent_exploration.py:125), z [B,L] -> out [B,Cout,H,W]. */
+int pu_fcomb_fwd(pu_ctx*, const float* feat, int64_t feat_bstride, const float* z, float* out, int B, void* stream);
+/* backward of the LAST pu_fcomb_fwd: dout -> dfeat (nullable; [B,F0,H,W] dense), dz (nullable; [B,L]),
+ * parameter grads ADDED into flat_grads. */
+int pu_fcomb_bwd(pu_ctx*, const float* dout, float* dfeat, float* dz, void* stream);
+
+/* ---- fused training step (replaces model.elbo(...) + loss.backward(), train_prob_unet_model.py:133-140) -- */
+/* eps: [M,B,L] reparameterisation noise (required: the caller owns the RNG, explicit for parity).
+ * out_scalars: PU_NUM_SCALARS floats; out_kl: [B]. with_backward != 0 also runs the whole backward and WRITES
+ * d(total)/d(param) into flat_grads (all entries, zeros for dead parameters). */
+int pu_elbo_fwd_bwd(pu_ctx*, const float* x, const float* target, const float* eps, int B, int M, int recon_kind,
+                    float beta0, float beta1, float beta2, float alpha, int train, uint64_t drop_seed,
+                    int with_backward, float* out_scalars, float* out_kl, void* stream);
+
+/* ---- sampling (replaces n x model(x, training=False), train_prob_unet_model.py:244-247, and
+ *      latent_exploration.py:119-129): U-Net + prior (or posterior if target given) ONCE, then n x Fcomb. ---- */
+/* eps [n,B,L]; out [B,n,Cout,H,W]; mu/sigma [B,L] nullable. */
+int pu_sample(pu_ctx*, const float* x, const float* target_or_null, const float* eps, int B, int n,
+              float* out, float* mu, float* sigma, void* stream);
+
+/* ---- introspection for bench/roofline ------------------------------------------------------------------ */
+int64_t pu_workspace_bytes(pu_ctx*);
+/* conv + matmul FLOPs (2*MAC) of one ELBO forward for batch B, members M (BASELINE.md §2 counting). */
+double pu_elbo_fwd_flops(pu_ctx*, int B, int M);
+
+/* ---- single-op entry points (used by tests/ to pin each kernel against a torch fp32 reference) ----------- */
+/* 3x3 (ks=3) or 1x1 (ks=1) convolution on NCHW fp32 tensors through the engine's NHWC implicit-GEMM kernels in
+ * `dtype`. mode 0: y = conv(x,w)+b (relu optional); 1: dx = dgrad(dy,w); 2: dw = wgrad(dy,x) (w/dw in [Cout,Cin,ks,ks]).
+ * All pointers device fp32. Syncs the stream. */
+int pu_op_conv(int dtype, int mode, int ks, int relu, int B, int Cin, int Cout, int H, int W,
+               const float* x, const float* w, const float* bias, const float* dy, float* out, void* stream);
+/* GroupNorm(+scale/shift)+SiLU with optional 2x resample (0 none, 1 avg-pool down, 2 nearest up), forward and
+ * backward, on NCHW fp32 tensors. Syncs. */
+int pu_op_gnsilu(int dtype, int resample, int B, int C, int H, int W, const float* x, const float* gamma,
+                 const float* beta, const float* scale_shift_or_null, float* y,
+                 const float* dy_or_null, float* dx, float* dgamma, float* dbeta, float* dscale_shift, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PROBUNET_H */

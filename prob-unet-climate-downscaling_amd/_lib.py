@@ -1,0 +1,89 @@
+"""ctypes binding of libprobunet.so (include/probunet.h). No CPU fallback: loading fails loudly."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libprobunet.so")
+
+PU_MAX_LEVELS = 8
+PU_F32, PU_F16, PU_BF16 = 0, 1, 2
+PU_PRIOR, PU_POSTERIOR = 0, 1
+PU_RECON_AFCRPS, PU_RECON_L1 = 0, 1
+PU_S_TOTAL, PU_S_RECON, PU_S_KL_MEAN, PU_S_KL2_MEAN, PU_NUM_SCALARS = 0, 1, 2, 3, 8
+DTYPES = {"f32": PU_F32, "fp32": PU_F32, "float32": PU_F32, "f16": PU_F16, "fp16": PU_F16, "float16": PU_F16,
+          "bf16": PU_BF16, "bfloat16": PU_BF16}
+
+
+class PuConfig(C.Structure):
+    _fields_ = [("input_channels", C.c_int32), ("num_classes", C.c_int32), ("latent_dim", C.c_int32), ("depth", C.c_int32),
+                ("num_filters", C.c_int32 * PU_MAX_LEVELS), ("model_channels", C.c_int32),
+                ("channel_mult", C.c_int32 * PU_MAX_LEVELS), ("H", C.c_int32), ("W", C.c_int32),
+                ("max_batch", C.c_int32), ("max_members", C.c_int32), ("dtype", C.c_int32), ("dropout_p", C.c_float)]
+
+
+class PuParamDesc(C.Structure):
+    _fields_ = [("name", C.c_char * 96), ("ndim", C.c_int32), ("shape", C.c_int32 * 4), ("offset", C.c_int64),
+                ("is_buffer", C.c_int32)]
+
+
+class ProbUNetLibraryError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """Load libprobunet.so once. torch must already be imported so that the HIP runtime it bundles
+    (libamdhip64.so.7) is the one the library binds to."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ProbUNetLibraryError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C prob-unet-climate-downscaling_amd/csrc`). There is no CPU fallback.")
+    import torch  # noqa: F401  (loads the HIP runtime first)
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, u64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_float
+    L.pu_abi_version.restype = i32
+    L.pu_last_error.restype = C.c_char_p; L.pu_last_error.argtypes = [vp]
+    L.pu_create.restype = i32; L.pu_create.argtypes = [C.POINTER(PuConfig), i32, C.POINTER(vp)]
+    L.pu_destroy.restype = i32; L.pu_destroy.argtypes = [vp]
+    L.pu_param_table.restype = i32; L.pu_param_table.argtypes = [vp, C.POINTER(C.POINTER(PuParamDesc)), C.POINTER(i32)]
+    L.pu_param_count.restype = i64; L.pu_param_count.argtypes = [vp]
+    L.pu_workspace_bytes.restype = i64; L.pu_workspace_bytes.argtypes = [vp]
+    L.pu_bind_params.restype = i32; L.pu_bind_params.argtypes = [vp, vp, vp]
+    L.pu_params_changed.restype = i32; L.pu_params_changed.argtypes = [vp]
+    L.pu_unet_fwd.restype = i32; L.pu_unet_fwd.argtypes = [vp, vp, vp, i32, i32, u64, vp]
+    L.pu_unet_bwd.restype = i32; L.pu_unet_bwd.argtypes = [vp, vp, vp]
+    L.pu_gauss_fwd.restype = i32; L.pu_gauss_fwd.argtypes = [vp, i32, vp, vp, vp, vp, i32, vp]
+    L.pu_gauss_bwd.restype = i32; L.pu_gauss_bwd.argtypes = [vp, i32, vp, vp, vp]
+    L.pu_fcomb_fwd.restype = i32; L.pu_fcomb_fwd.argtypes = [vp, vp, i64, vp, vp, i32, vp]
+    L.pu_fcomb_bwd.restype = i32; L.pu_fcomb_bwd.argtypes = [vp, vp, vp, vp, vp]
+    L.pu_elbo_fwd_bwd.restype = i32
+    L.pu_elbo_fwd_bwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, f32, f32, f32, f32, i32, u64, i32, vp, vp, vp]
+    L.pu_sample.restype = i32; L.pu_sample.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp]
+    L.pu_elbo_fwd_flops.restype = C.c_double; L.pu_elbo_fwd_flops.argtypes = [vp, i32, i32]
+    L.pu_op_conv.restype = i32
+    L.pu_op_conv.argtypes = [i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]
+    L.pu_op_gnsilu.restype = i32
+    L.pu_op_gnsilu.argtypes = [i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    _lib = L
+    return L
+
+
+def check(rc, ctx=None, what=""):
+    if rc != 0:
+        msg = lib().pu_last_error(ctx)
+        raise ProbUNetLibraryError(f"{what} failed (status {rc}): {msg.decode() if msg else ''}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def current_stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

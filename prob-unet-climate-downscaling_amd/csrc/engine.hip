@@ -1,0 +1,971 @@
+// libprobunet engine: static plan (tensors in one HBM arena), forward/backward sequencing, C ABI.
+// Mirrors, as a static graph, ProbabilisticUNet.forward/elbo (src/prob_unet.py:194-317) and UNet/UNetBlock
+// (src/networks.py:134-333) of the reference; see include/probunet.h for the boundary.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <string>
+#include <vector>
+
+#include "../../include/probunet.h"
+#include "pu_kernels.h"
+
+using namespace pu;
+
+#define PU_ABI 1
+
+namespace {
+
+struct ConvL {
+  int cin = 0, cout = 0, ks = 3;
+  int64_t w_off = -1, b_off = -1;
+  long pk_fwd = -1, pk_bwd = -1;       // element offsets into the packed-weight buffer
+  int cin_pk = 0, rows_fwd = 0;        // forward pack: [rows_fwd][taps][cin_pk]
+  int cout_pk = 0, rows_bwd = 0;       // dgrad pack:   [rows_bwd][taps][cout_pk]
+  bool need_dgrad = true;
+};
+struct GNL {
+  int C = 0, G = 0, nchunk = 1;
+  int64_t g_off = -1, b_off = -1, ss_off = -1;   // gamma, beta, affine.bias (scale|shift) offsets
+  float* stat = nullptr; float* coef = nullptr;
+  uint32_t drop_stream = 0; bool dropout = false; int resample = RS_NONE;
+};
+struct Act { TV v; TV g; int flag = -1; };          // value view, gradient view, index of the shared "grad written" flag
+
+enum SkipKind { SK_NONE, SK_IDENTITY, SK_RESAMPLE, SK_CONV };
+struct Block {
+  std::string name; bool is_block = true;
+  int cin = 0, cout = 0; bool up = false, down = false; int skip = SK_NONE;
+  Act x, a0, c0, h1, out, skin;
+  GNL n0, n1; ConvL conv0, conv1, skipc;
+};
+struct GaussNet {
+  std::vector<ConvL> convs; std::vector<Act> outs; std::vector<Act> ins;   // ins[i] is the input of conv i
+  std::vector<int> pool_before;                                            // 1 if a maxpool precedes conv i
+  int64_t wmu = -1, bmu = -1, wls = -1, bls = -1;
+  float *hbuf = nullptr, *mu = nullptr, *ls = nullptr, *dmu = nullptr, *dls = nullptr;
+  int lastB = 0;
+};
+
+}  // namespace
+
+struct pu_ctx {
+  pu_config cfg; int device = 0; std::string err;
+  int dt = 0; size_t esz = 4;
+  std::vector<pu_param_desc> table; int64_t nparams = 0;
+  float* params = nullptr; float* grads = nullptr; bool packed_valid = false;
+  char* arena = nullptr; size_t arena_size = 0, arena_used = 0; bool planning = true;
+  void* packed = nullptr; long packed_elems = 0; std::vector<PackDesc> descs; PackDesc* descs_dev = nullptr;
+  std::vector<char> flags;
+  // network
+  std::vector<Block> enc, dec; GNL out_norm; ConvL out_conv; Act out_a, feat;
+  Act x_in, xy_in;
+  GaussNet prior, post;
+  int64_t fc_w0 = -1, fc_b0 = -1, fc_w1 = -1, fc_b1 = -1, fc_w2 = -1, fc_b2 = -1;
+  // scratch
+  float* gn_part = nullptr; float* gn_part2 = nullptr; float* gn_coef2 = nullptr; float* bias_part = nullptr; TV dv_scratch;
+  float *z = nullptr, *dz = nullptr, *preds = nullptr, *dpreds = nullptr, *kl = nullptr, *kl2 = nullptr, *scal = nullptr;
+  Act fc_feat;                      // standalone fcomb input (converted) + its gradient
+  float* fc_z = nullptr; int fc_B = 0; int fc_bcast = 0;
+  int unet_B = 0, unet_train = 0; uint64_t unet_seed = 0;
+  int max_gn_c = 0;
+};
+
+static std::string g_create_err;
+
+// ------------------------------------------------------------------ helpers
+#define CKH(expr)                                                                                       \
+  do {                                                                                                  \
+    hipError_t _e = (expr);                                                                             \
+    if (_e != hipSuccess) {                                                                             \
+      char _b[512]; snprintf(_b, sizeof _b, "%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+      c->err = _b; return PU_ERR_HIP;                                                                   \
+    }                                                                                                   \
+  } while (0)
+#define FAIL(code, ...)                                            \
+  do { char _b[512]; snprintf(_b, sizeof _b, __VA_ARGS__); c->err = _b; return code; } while (0)
+
+template <typename F> static int dispatch(pu_ctx* c, F&& f) {
+  switch (c->dt) {
+    case PU_F32: return f(float{});
+    case PU_F16: return f(f16{});
+    case PU_BF16: return f(bf16{});
+  }
+  return PU_ERR_INVALID;
+}
+
+static void* arena_alloc(pu_ctx* c, size_t bytes) {
+  size_t off = (c->arena_used + 255) & ~(size_t)255;
+  c->arena_used = off + bytes;
+  if (c->planning) return nullptr;
+  return c->arena + off;
+}
+static TV alloc_tv(pu_ctx* c, int B, int H, int W, int C) {
+  TV t; t.B = B; t.H = H; t.W = W; t.C = C; t.ld = C;
+  t.p = arena_alloc(c, (size_t)B * H * W * C * c->esz);
+  return t;
+}
+static float* alloc_f32(pu_ctx* c, size_t n) { return (float*)arena_alloc(c, n * sizeof(float)); }
+static TV view_c(const TV& t, int coff, int C, size_t esz) {
+  TV v = t; v.C = C; v.p = t.p ? (char*)t.p + (size_t)coff * esz : nullptr; return v;
+}
+static TV with_b(TV t, int B) { t.B = B; return t; }
+static int new_flag(pu_ctx* c) { c->flags.push_back(0); return (int)c->flags.size() - 1; }
+static Act alloc_act(pu_ctx* c, int B, int H, int W, int C, bool need_grad = true) {
+  Act a; a.v = alloc_tv(c, B, H, W, C);
+  if (need_grad) { a.g = alloc_tv(c, B, H, W, C); a.flag = new_flag(c); }
+  return a;
+}
+static Act view_act(const Act& a, int coff, int C, size_t esz) {
+  Act v; v.v = view_c(a.v, coff, C, esz); v.g = view_c(a.g, coff, C, esz); v.flag = a.flag; return v;
+}
+// returns whether the gradient already holds a contribution (=> accumulate) and marks it written
+static int take_acc(pu_ctx* c, const Act& a) { int r = c->flags[a.flag]; c->flags[a.flag] = 1; return r; }
+
+static int64_t add_param(pu_ctx* c, const std::string& name, std::initializer_list<int> shape, bool is_buffer = false) {
+  pu_param_desc d; memset(&d, 0, sizeof d);
+  snprintf(d.name, sizeof d.name, "%s", name.c_str());
+  d.ndim = (int)shape.size(); int i = 0; int64_t n = 1;
+  for (int s : shape) { d.shape[i++] = s; n *= s; }
+  d.is_buffer = is_buffer ? 1 : 0;
+  if (is_buffer) d.offset = -1;
+  else { d.offset = c->nparams; c->nparams += n; }
+  c->table.push_back(d);
+  return d.offset;
+}
+
+static void setup_conv(pu_ctx* c, ConvL& L, int cin, int cout, int ks, int64_t w_off, int64_t b_off, bool need_dgrad) {
+  L.cin = cin; L.cout = cout; L.ks = ks; L.w_off = w_off; L.b_off = b_off; L.need_dgrad = need_dgrad;
+  const int taps = ks * ks;
+  L.cin_pk = rup(cin, 32); L.rows_fwd = rup(cout, 32);
+  L.pk_fwd = c->packed_elems; c->packed_elems += (long)L.rows_fwd * taps * L.cin_pk;
+  PackDesc d; d.src_off = w_off; d.dst_off = L.pk_fwd; d.Cout = cout; d.Cin = cin; d.taps = taps; d.rows_pk = L.rows_fwd; d.k_pk = L.cin_pk; d.mode = 0;
+  c->descs.push_back(d);
+  if (need_dgrad) {
+    L.cout_pk = rup(cout, 32); L.rows_bwd = rup(cin, 32);
+    L.pk_bwd = c->packed_elems; c->packed_elems += (long)L.rows_bwd * taps * L.cout_pk;
+    d.dst_off = L.pk_bwd; d.rows_pk = L.rows_bwd; d.k_pk = L.cout_pk; d.mode = 1;
+    c->descs.push_back(d);
+  }
+}
+static int gn_groups(int C) { int g = C / 4; return g < 32 ? g : 32; }
+static int gn_chunks(long HW) { long n = HW / 256; if (n < 1) n = 1; if (n > 64) n = 64; return (int)n; }
+static void setup_gn(pu_ctx* c, GNL& n, int C, long HW, int64_t g_off, int64_t b_off, int64_t ss_off, int resample, bool dropout, uint32_t stream) {
+  n.C = C; n.G = gn_groups(C); n.nchunk = gn_chunks(HW); n.g_off = g_off; n.b_off = b_off; n.ss_off = ss_off; n.resample = resample;
+  n.dropout = dropout; n.drop_stream = stream;
+  const int mb = c->cfg.max_batch;
+  n.stat = alloc_f32(c, (size_t)mb * n.G * 2);
+  n.coef = alloc_f32(c, (size_t)mb * C * 2);
+  if (C > c->max_gn_c) c->max_gn_c = C;
+}
+
+// ------------------------------------------------------------------ plan construction
+struct Spec { std::string name; bool is_block; int cin, cout; bool up, down, concat; int level; };
+
+static int build_plan(pu_ctx* c) {
+  const pu_config& cf = c->cfg;
+  const int mb = cf.max_batch, D = cf.depth, mc = cf.model_channels;
+  const size_t esz = c->esz;
+  c->table.clear(); c->nparams = 0; c->packed_elems = 0; c->descs.clear(); c->flags.clear();
+  c->enc.clear(); c->dec.clear(); c->arena_used = 0; c->max_gn_c = 0;
+  c->prior = GaussNet(); c->post = GaussNet();
+  const int emb = mc * 4;
+  add_param(c, "unet.map_label.weight", {emb, 1});
+
+  // ---- specs (networks.py:259-295)
+  std::vector<Spec> es, ds;
+  int cout = cf.input_channels;
+  for (int lv = 0; lv < D; ++lv) {
+    const int r = 128 >> lv;
+    char p[64]; snprintf(p, sizeof p, "unet.enc.%dx%d", r, r);
+    if (lv == 0) { int cin = cout; cout = mc * cf.channel_mult[0]; es.push_back({std::string(p) + "_conv", false, cin, cout, false, false, false, lv}); }
+    else es.push_back({std::string(p) + "_down", true, cout, cout, false, true, false, lv});
+    for (int i = 0; i < 2; ++i) { int cin = cout; cout = mc * cf.channel_mult[lv]; es.push_back({std::string(p) + "_block" + std::to_string(i), true, cin, cout, false, false, false, lv}); }
+  }
+  std::vector<int> skips; for (auto& s : es) skips.push_back(s.cout);
+  std::vector<int> skip_of_dec;
+  {
+    std::vector<int> stack; for (int i = 0; i < (int)es.size(); ++i) stack.push_back(i);
+    for (int lv = D - 1; lv >= 0; --lv) {
+      const int r = 128 >> lv;
+      char p[64]; snprintf(p, sizeof p, "unet.dec.%dx%d", r, r);
+      if (lv == D - 1) {
+        ds.push_back({std::string(p) + "_in0", true, cout, cout, false, false, false, lv}); skip_of_dec.push_back(-1);
+        ds.push_back({std::string(p) + "_in1", true, cout, cout, false, false, false, lv}); skip_of_dec.push_back(-1);
+      } else { ds.push_back({std::string(p) + "_up", true, cout, cout, true, false, false, lv}); skip_of_dec.push_back(-1); }
+      for (int i = 0; i < 3; ++i) {
+        const int si = stack.back(); stack.pop_back();
+        const int cin = cout + es[si].cout; cout = mc * cf.channel_mult[lv];
+        ds.push_back({std::string(p) + "_block" + std::to_string(i), true, cin, cout, false, false, true, lv}); skip_of_dec.push_back(si);
+      }
+    }
+  }
+  const int c_last = cout;
+  auto chk8 = [&](int ch) { return ch % 8 == 0; };
+  for (auto& s : es) if (!chk8(s.cout)) FAIL(PU_ERR_INVALID, "channel count %d of %s is not a multiple of 8", s.cout, s.name.c_str());
+  for (int i = 0; i < D; ++i) if (!chk8(cf.num_filters[i])) FAIL(PU_ERR_INVALID, "num_filters[%d]=%d is not a multiple of 8", i, cf.num_filters[i]);
+
+  // ---- tensors: inputs
+  const int H = cf.H, W = cf.W;
+  const int cin_pad = rup(cf.input_channels, 8), cxy_pad = rup(cf.input_channels + cf.num_classes, 8);
+  c->x_in = alloc_act(c, mb, H, W, cin_pad, false);
+  c->xy_in = alloc_act(c, mb, H, W, cxy_pad, false);
+
+  // ---- concat buffers for decoder blocks; encoder outputs live inside them (zero-copy torch.cat, networks.py:328-329)
+  std::vector<Act> cat(ds.size());
+  for (size_t j = 0; j < ds.size(); ++j)
+    if (ds[j].concat) { const int r_h = H >> ds[j].level, r_w = W >> ds[j].level; cat[j] = alloc_act(c, mb, r_h, r_w, ds[j].cin); }
+  std::vector<Act> enc_out(es.size());
+  for (size_t j = 0; j < ds.size(); ++j)
+    if (ds[j].concat) { const int si = skip_of_dec[j]; const int cx = ds[j].cin - es[si].cout; enc_out[si] = view_act(cat[j], cx, es[si].cout, esz); }
+
+  uint32_t drop_stream = 1;
+  auto build_block = [&](const Spec& s, Block& b, const Act& xin, const Act& outa, int inH, int inW) {
+    b.name = s.name; b.is_block = s.is_block; b.cin = s.cin; b.cout = s.cout; b.up = s.up; b.down = s.down;
+    b.x = xin; b.out = outa;
+    const int oH = s.down ? inH / 2 : (s.up ? inH * 2 : inH), oW = s.down ? inW / 2 : (s.up ? inW * 2 : inW);
+    const std::string& p = s.name;
+    if (!s.is_block) {
+      const int64_t w = add_param(c, p + ".weight", {s.cout, s.cin, 3, 3});
+      const int64_t bb = add_param(c, p + ".bias", {s.cout});
+      setup_conv(c, b.conv0, s.cin, s.cout, 3, w, bb, false);
+      return;
+    }
+    const int64_t g0 = add_param(c, p + ".norm0.weight", {s.cin});
+    const int64_t b0 = add_param(c, p + ".norm0.bias", {s.cin});
+    const int64_t w0 = add_param(c, p + ".conv0.weight", {s.cout, s.cin, 3, 3});
+    const int64_t bb0 = add_param(c, p + ".conv0.bias", {s.cout});
+    if (s.up || s.down) add_param(c, p + ".conv0.resample_filter", {1, 1, 2, 2}, true);
+    add_param(c, p + ".affine.weight", {2 * s.cout, emb});
+    const int64_t ab = add_param(c, p + ".affine.bias", {2 * s.cout});
+    const int64_t g1 = add_param(c, p + ".norm1.weight", {s.cout});
+    const int64_t b1 = add_param(c, p + ".norm1.bias", {s.cout});
+    const int64_t w1 = add_param(c, p + ".conv1.weight", {s.cout, s.cout, 3, 3});
+    const int64_t bb1 = add_param(c, p + ".conv1.bias", {s.cout});
+    b.skip = s.cin != s.cout ? SK_CONV : ((s.up || s.down) ? SK_RESAMPLE : SK_IDENTITY);
+    if (b.skip == SK_CONV) {
+      const int64_t ws = add_param(c, p + ".skip.weight", {s.cout, s.cin, 1, 1});
+      const int64_t bs = add_param(c, p + ".skip.bias", {s.cout});
+      if (s.up || s.down) add_param(c, p + ".skip.resample_filter", {1, 1, 2, 2}, true);
+      setup_conv(c, b.skipc, s.cin, s.cout, 1, ws, bs, true);
+    } else if (b.skip == SK_RESAMPLE) add_param(c, p + ".skip.resample_filter", {1, 1, 2, 2}, true);
+    const int rs = s.down ? RS_DOWN : (s.up ? RS_UP : RS_NONE);
+    setup_gn(c, b.n0, s.cin, (long)inH * inW, g0, b0, -1, rs, false, 0);
+    setup_conv(c, b.conv0, s.cin, s.cout, 3, w0, bb0, true);
+    setup_gn(c, b.n1, s.cout, (long)oH * oW, g1, b1, ab, RS_NONE, true, drop_stream++);
+    setup_conv(c, b.conv1, s.cout, s.cout, 3, w1, bb1, true);
+    b.a0 = alloc_act(c, mb, oH, oW, s.cin);
+    b.c0 = alloc_act(c, mb, oH, oW, s.cout);
+    b.h1 = alloc_act(c, mb, oH, oW, s.cout);
+    if ((s.up || s.down) && b.skip != SK_IDENTITY) b.skin = alloc_act(c, mb, oH, oW, s.cin);
+  };
+
+  // ---- encoder
+  c->enc.resize(es.size());
+  {
+    Act cur = c->x_in; int curH = H, curW = W;
+    for (size_t i = 0; i < es.size(); ++i) {
+      build_block(es[i], c->enc[i], cur, enc_out[i], curH, curW);
+      if (es[i].down) { curH /= 2; curW /= 2; }
+      cur = enc_out[i];
+    }
+    // ---- decoder
+    c->dec.resize(ds.size());
+    for (size_t j = 0; j < ds.size(); ++j) {
+      Act xin = ds[j].concat ? cat[j] : cur;
+      const int oH = ds[j].up ? curH * 2 : curH, oW = ds[j].up ? curW * 2 : curW;
+      Act outa;
+      if (j + 1 < ds.size() && ds[j + 1].concat) outa = view_act(cat[j + 1], 0, ds[j].cout, esz);
+      else outa = alloc_act(c, mb, oH, oW, ds[j].cout);
+      build_block(ds[j], c->dec[j], xin, outa, curH, curW);
+      curH = oH; curW = oW; cur = outa;
+    }
+    // ---- output head (networks.py:296-297,331)
+    const int64_t og = add_param(c, "unet.out_norm.weight", {c_last});
+    const int64_t ob = add_param(c, "unet.out_norm.bias", {c_last});
+    const int64_t ow = add_param(c, "unet.out_conv.weight", {cf.num_filters[0], c_last, 3, 3});
+    const int64_t obb = add_param(c, "unet.out_conv.bias", {cf.num_filters[0]});
+    setup_gn(c, c->out_norm, c_last, (long)H * W, og, ob, -1, RS_NONE, false, 0);
+    setup_conv(c, c->out_conv, c_last, cf.num_filters[0], 3, ow, obb, true);
+    c->out_a = alloc_act(c, mb, H, W, c_last);
+    c->feat = alloc_act(c, mb, H, W, cf.num_filters[0]);
+  }
+
+  // ---- Gaussian encoders (prob_unet.py:19-54)
+  auto build_gauss = [&](GaussNet& g, const char* net, const Act& in0, int cin0_logical, int cin0_alloc) {
+    Act cur = in0; int curH = H, curW = W; int cin = cin0_logical; int idx = 0; (void)cin0_alloc;
+    for (int lv = 0; lv < D; ++lv) {
+      bool pooled = false;
+      if (lv != 0) {
+        idx += 1;
+        Act pl = alloc_act(c, mb, curH / 2, curW / 2, cin);
+        g.ins.push_back(pl); pooled = true; curH /= 2; curW /= 2; cur = pl;
+      }
+      for (int k = 0; k < 3; ++k) {
+        const int co = cf.num_filters[lv];
+        const int64_t w = add_param(c, std::string(net) + ".encoder." + std::to_string(idx) + ".weight", {co, cin, 3, 3});
+        const int64_t b = add_param(c, std::string(net) + ".encoder." + std::to_string(idx) + ".bias", {co});
+        ConvL L; setup_conv(c, L, cin, co, 3, w, b, !(lv == 0 && k == 0));
+        g.convs.push_back(L);
+        if (!(pooled && k == 0)) g.ins.push_back(cur);
+        g.pool_before.push_back(pooled && k == 0 ? 1 : 0);
+        Act o = alloc_act(c, mb, curH, curW, co);
+        g.outs.push_back(o); cur = o; cin = co; idx += 2;
+      }
+    }
+    const int cf_last = cf.num_filters[D - 1], L = cf.latent_dim;
+    g.wmu = add_param(c, std::string(net) + ".conv_mu.weight", {L, cf_last, 1, 1});
+    g.bmu = add_param(c, std::string(net) + ".conv_mu.bias", {L});
+    g.wls = add_param(c, std::string(net) + ".conv_log_sigma.weight", {L, cf_last, 1, 1});
+    g.bls = add_param(c, std::string(net) + ".conv_log_sigma.bias", {L});
+    g.hbuf = alloc_f32(c, (size_t)mb * cf_last);
+    g.mu = alloc_f32(c, (size_t)mb * L); g.ls = alloc_f32(c, (size_t)mb * L);
+    g.dmu = alloc_f32(c, (size_t)mb * L); g.dls = alloc_f32(c, (size_t)mb * L);
+  };
+  build_gauss(c->prior, "prior", c->x_in, cf.input_channels, cin_pad);
+  build_gauss(c->post, "posterior", c->xy_in, cf.input_channels + cf.num_classes, cxy_pad);
+
+  // ---- Fcomb (prob_unet.py:99-105)
+  const int F = cf.num_filters[0], L = cf.latent_dim, Co = cf.num_classes, MM_ = cf.max_members;
+  c->fc_w0 = add_param(c, "fcomb.layers.0.weight", {F, F + L, 1, 1});
+  c->fc_b0 = add_param(c, "fcomb.layers.0.bias", {F});
+  c->fc_w1 = add_param(c, "fcomb.layers.2.weight", {F, F, 1, 1});
+  c->fc_b1 = add_param(c, "fcomb.layers.2.bias", {F});
+  c->fc_w2 = add_param(c, "fcomb.layers.4.weight", {Co, F, 1, 1});
+  c->fc_b2 = add_param(c, "fcomb.layers.4.bias", {Co});
+  if (F != 8 && F != 16 && F != 32) FAIL(PU_ERR_INVALID, "num_filters[0]=%d unsupported by the fused Fcomb kernel (8, 16 or 32)", F);
+  if (Co > F) FAIL(PU_ERR_INVALID, "num_classes %d > num_filters[0] %d unsupported", Co, F);
+  if (MM_ > 16) FAIL(PU_ERR_INVALID, "max_members %d > 16 unsupported by the fused afCRPS kernel", MM_);
+
+  // ---- scratch
+  const long HW = (long)H * W;
+  c->gn_part = alloc_f32(c, (size_t)mb * 64 * c->max_gn_c * 2);
+  c->gn_part2 = alloc_f32(c, (size_t)mb * 64 * c->max_gn_c * 2);
+  c->gn_coef2 = alloc_f32(c, (size_t)mb * c->max_gn_c * 3);
+  c->bias_part = alloc_f32(c, (size_t)256 * 1024);
+  {  // dv scratch: the largest GroupNorm input
+    size_t mx = 0;
+    auto upd = [&](const Block& b) { if (b.is_block) { size_t a = (size_t)b.x.v.H * b.x.v.W * b.x.v.C, q = (size_t)b.c0.v.H * b.c0.v.W * b.c0.v.C; if (a > mx) mx = a; if (q > mx) mx = q; } };
+    for (auto& b : c->enc) upd(b);
+    for (auto& b : c->dec) upd(b);
+    size_t o = (size_t)H * W * c_last; if (o > mx) mx = o;
+    c->dv_scratch = TV(); c->dv_scratch.p = arena_alloc(c, mx * mb * esz);
+  }
+  c->z = alloc_f32(c, (size_t)MM_ * mb * L); c->dz = alloc_f32(c, (size_t)MM_ * mb * L);
+  c->preds = alloc_f32(c, (size_t)mb * MM_ * Co * HW); c->dpreds = alloc_f32(c, (size_t)mb * MM_ * Co * HW);
+  c->kl = alloc_f32(c, mb); c->kl2 = alloc_f32(c, mb); c->scal = alloc_f32(c, PU_NUM_SCALARS);
+  c->fc_feat = alloc_act(c, mb, H, W, F);
+  c->fc_z = alloc_f32(c, (size_t)mb * L);
+  return PU_OK;
+}
+
+// ------------------------------------------------------------------ op wrappers
+static const float* P(pu_ctx* c, int64_t off) { return off < 0 ? nullptr : c->params + off; }
+static float* G(pu_ctx* c, int64_t off) { return off < 0 ? nullptr : c->grads + off; }
+
+static int ensure_packed(pu_ctx* c, hipStream_t s) {
+  if (!c->params) FAIL(PU_ERR_STATE, "pu_bind_params has not been called");
+  if (c->packed_valid) return PU_OK;
+  int r = dispatch(c, [&](auto t) -> int {
+    typedef decltype(t) T;
+    CKH(launch_pack<T>(c->params, c->packed, c->descs_dev, (int)c->descs.size(), s));
+    return PU_OK;
+  });
+  if (r == PU_OK) c->packed_valid = true;
+  return r;
+}
+
+template <typename T>
+static int conv_fwd(pu_ctx* c, const ConvL& L, TV in, TV out, int B, bool relu, const TV* res, int accumulate, hipStream_t s) {
+  ConvArgs a; memset(&a, 0, sizeof a);
+  a.in = in.p; a.in_ld = in.ld;
+  a.Cin = in.C;                       // channels present in the tensor (>= L.cin; extra planes meet zero-padded weights)
+  a.wpk = (char*)c->packed + (size_t)L.pk_fwd * c->esz; a.cin_pk = L.cin_pk; a.cout_pk = L.rows_fwd; a.taps = L.ks * L.ks;
+  a.bias = P(c, L.b_off);
+  a.res = res ? res->p : nullptr; a.res_ld = res ? res->ld : 0;
+  a.out = out.p; a.out_ld = out.ld; a.Cout = L.cout;
+  a.B = B; a.H = out.H; a.W = out.W; a.relu = relu ? 1 : 0; a.accumulate = accumulate;
+  if (a.Cin > L.cin_pk) a.Cin = L.cin_pk;
+  CKH(launch_conv<T>(a, s));
+  return PU_OK;
+}
+// dx (+)= dgrad(dy)
+template <typename T>
+static int conv_dgrad(pu_ctx* c, const ConvL& L, TV dy, TV dx, int B, int accumulate, hipStream_t s) {
+  ConvArgs a; memset(&a, 0, sizeof a);
+  a.in = dy.p; a.in_ld = dy.ld; a.Cin = L.cout;
+  a.wpk = (char*)c->packed + (size_t)L.pk_bwd * c->esz; a.cin_pk = L.cout_pk; a.cout_pk = L.rows_bwd; a.taps = L.ks * L.ks;
+  a.bias = nullptr; a.res = nullptr;
+  a.out = dx.p; a.out_ld = dx.ld;
+  a.Cout = dx.C;                      // write every allocated plane (planes >= L.cin receive zeros from zero-padded weights)
+  if (a.Cout > L.rows_bwd) a.Cout = L.rows_bwd;
+  a.B = B; a.H = dx.H; a.W = dx.W; a.relu = 0; a.accumulate = accumulate;
+  CKH(launch_conv<T>(a, s));
+  return PU_OK;
+}
+template <typename T>
+static int conv_wgrad(pu_ctx* c, const ConvL& L, TV dy, TV in, int B, hipStream_t s) {
+  WgradArgs a; memset(&a, 0, sizeof a);
+  a.dy = dy.p; a.dy_ld = dy.ld; a.Cout = L.cout; a.in = in.p; a.in_ld = in.ld; a.Cin = L.cin;
+  a.dw = G(c, L.w_off); a.B = B; a.H = dy.H; a.W = dy.W; a.taps = L.ks * L.ks;
+  CKH(launch_wgrad<T>(a, s));
+  return PU_OK;
+}
+static int bias_chunks(long npix) { long n = npix / 256; if (n < 1) n = 1; if (n > 256) n = 256; return (int)n; }
+template <typename T>
+static int conv_bgrad(pu_ctx* c, TV dy, int B, float* d0, float* d1, hipStream_t s) {
+  TV t = with_b(dy, B);
+  CKH(launch_bias_grad<T>(t, d0, d1, c->bias_part, bias_chunks((long)B * dy.H * dy.W), s));
+  return PU_OK;
+}
+
+static GNArgs gn_args(pu_ctx* c, const GNL& n, TV x, TV y, int B, int train, uint64_t seed) {
+  GNArgs a; memset(&a, 0, sizeof a);
+  a.x = with_b(x, B); a.y = with_b(y, B); a.G = n.G; a.eps = 1e-5f;
+  a.gamma = P(c, n.g_off); a.beta = P(c, n.b_off);
+  a.scale = n.ss_off >= 0 ? P(c, n.ss_off) : nullptr; a.shift = n.ss_off >= 0 ? P(c, n.ss_off + n.C) : nullptr;
+  a.resample = n.resample;
+  a.drop_p = (n.dropout && train) ? c->cfg.dropout_p : 0.f; a.drop_seed = seed; a.drop_stream = n.drop_stream;
+  a.part = c->gn_part; a.stat = n.stat; a.coef = n.coef; a.nchunk = n.nchunk;
+  return a;
+}
+template <typename T>
+static int gn_fwd(pu_ctx* c, const GNL& n, TV x, TV y, int B, int train, uint64_t seed, hipStream_t s) {
+  GNArgs a = gn_args(c, n, x, y, B, train, seed);
+  CKH(launch_gn_fwd<T>(a, s));
+  return PU_OK;
+}
+template <typename T>
+static int gn_bwd(pu_ctx* c, const GNL& n, TV x, TV y, TV dy, TV dx, int accumulate, int B, int train, uint64_t seed, hipStream_t s) {
+  GNBwdArgs a; memset(&a, 0, sizeof a);
+  a.f = gn_args(c, n, x, y, B, train, seed);
+  a.dy = with_b(dy, B);
+  a.dv = with_b(x, B); a.dv.p = c->dv_scratch.p; a.dv.ld = x.C;
+  a.dx = with_b(dx, B); a.accumulate = accumulate;
+  a.dgamma = G(c, n.g_off); a.dbeta = G(c, n.b_off);
+  a.dscale = n.ss_off >= 0 ? G(c, n.ss_off) : nullptr; a.dshift = n.ss_off >= 0 ? G(c, n.ss_off + n.C) : nullptr;
+  a.part2 = c->gn_part2; a.coef2 = c->gn_coef2;
+  CKH(launch_gn_bwd<T>(a, s));
+  return PU_OK;
+}
+
+// ------------------------------------------------------------------ U-Net forward / backward
+template <typename T>
+static int block_fwd(pu_ctx* c, Block& b, int B, int train, uint64_t seed, hipStream_t s) {
+  int r;
+  if (!b.is_block) return conv_fwd<T>(c, b.conv0, b.x.v, b.out.v, B, false, nullptr, 0, s);
+  // x = conv0(resample(silu(norm0(x))))            networks.py:168
+  if ((r = gn_fwd<T>(c, b.n0, b.x.v, b.a0.v, B, train, seed, s))) return r;
+  if ((r = conv_fwd<T>(c, b.conv0, b.a0.v, b.c0.v, B, false, nullptr, 0, s))) return r;
+  // x = silu(shift + norm1(x) * (scale + 1)); dropout   networks.py:170-177
+  if ((r = gn_fwd<T>(c, b.n1, b.c0.v, b.h1.v, B, train, seed, s))) return r;
+  // x = conv1(x) + skip(orig)                        networks.py:177-179
+  if (b.skip == SK_CONV) {
+    TV sin = b.x.v;
+    if (b.up || b.down) { CKH(launch_resample<T>(with_b(b.x.v, B), with_b(b.skin.v, B), b.down ? RS_DOWN : RS_UP, s)); sin = b.skin.v; }
+    if ((r = conv_fwd<T>(c, b.skipc, sin, b.out.v, B, false, nullptr, 0, s))) return r;
+    return conv_fwd<T>(c, b.conv1, b.h1.v, b.out.v, B, false, nullptr, 1, s);
+  }
+  if (b.skip == SK_RESAMPLE) {
+    CKH(launch_resample<T>(with_b(b.x.v, B), with_b(b.skin.v, B), b.down ? RS_DOWN : RS_UP, s));
+    return conv_fwd<T>(c, b.conv1, b.h1.v, b.out.v, B, false, &b.skin.v, 0, s);
+  }
+  return conv_fwd<T>(c, b.conv1, b.h1.v, b.out.v, B, false, &b.x.v, 0, s);
+}
+
+template <typename T>
+static int block_bwd(pu_ctx* c, Block& b, int B, int train, uint64_t seed, bool need_dx, hipStream_t s) {
+  int r;
+  TV dout = b.out.g;
+  if (!b.is_block) {
+    if ((r = conv_wgrad<T>(c, b.conv0, dout, b.x.v, B, s))) return r;
+    return conv_bgrad<T>(c, dout, B, G(c, b.conv0.b_off), nullptr, s);
+  }
+  // conv1
+  if ((r = conv_wgrad<T>(c, b.conv1, dout, b.h1.v, B, s))) return r;
+  if ((r = conv_bgrad<T>(c, dout, B, G(c, b.conv1.b_off), b.skip == SK_CONV ? G(c, b.skipc.b_off) : nullptr, s))) return r;
+  if ((r = conv_dgrad<T>(c, b.conv1, dout, b.h1.g, B, 0, s))) return r;
+  // skip path
+  if (b.skip == SK_CONV) {
+    TV sin = (b.up || b.down) ? b.skin.v : b.x.v;
+    if ((r = conv_wgrad<T>(c, b.skipc, dout, sin, B, s))) return r;
+    if (need_dx) {
+      if (b.up || b.down) {
+        if ((r = conv_dgrad<T>(c, b.skipc, dout, b.skin.g, B, 0, s))) return r;
+        CKH(launch_resample_bwd<T>(with_b(b.skin.g, B), with_b(b.x.g, B), b.down ? RS_DOWN : RS_UP, take_acc(c, b.x), s));
+      } else if ((r = conv_dgrad<T>(c, b.skipc, dout, b.x.g, B, take_acc(c, b.x), s))) return r;
+    }
+  } else if (need_dx) {
+    if (b.skip == SK_RESAMPLE) CKH(launch_resample_bwd<T>(with_b(dout, B), with_b(b.x.g, B), b.down ? RS_DOWN : RS_UP, take_acc(c, b.x), s));
+    else CKH(launch_add<T>(with_b(dout, B), with_b(b.x.g, B), take_acc(c, b.x), s));
+  }
+  // norm1 (+scale/shift, dropout) -> c0.g
+  if ((r = gn_bwd<T>(c, b.n1, b.c0.v, b.h1.v, b.h1.g, b.c0.g, 0, B, train, seed, s))) return r;
+  // conv0
+  if ((r = conv_wgrad<T>(c, b.conv0, b.c0.g, b.a0.v, B, s))) return r;
+  if ((r = conv_bgrad<T>(c, b.c0.g, B, G(c, b.conv0.b_off), nullptr, s))) return r;
+  if ((r = conv_dgrad<T>(c, b.conv0, b.c0.g, b.a0.g, B, 0, s))) return r;
+  // norm0 (+resample) -> x.g   (parameter gradients are needed even when dx is not)
+  TV dx = b.x.g; int acc = 0;
+  if (need_dx) acc = take_acc(c, b.x);
+  else { dx = with_b(b.x.v, B); dx.p = c->dv_scratch.p; dx.ld = b.x.v.C; }      // never happens for blocks (x always needs grad)
+  return gn_bwd<T>(c, b.n0, b.x.v, b.a0.v, b.a0.g, dx, acc, B, train, seed, s);
+}
+
+template <typename T>
+static int unet_forward(pu_ctx* c, int B, int train, uint64_t seed, hipStream_t s) {
+  int r;
+  for (auto& b : c->enc) if ((r = block_fwd<T>(c, b, B, train, seed, s))) return r;
+  for (auto& b : c->dec) if ((r = block_fwd<T>(c, b, B, train, seed, s))) return r;
+  Act& last = c->dec.back().out;
+  if ((r = gn_fwd<T>(c, c->out_norm, last.v, c->out_a.v, B, train, seed, s))) return r;
+  if ((r = conv_fwd<T>(c, c->out_conv, c->out_a.v, c->feat.v, B, false, nullptr, 0, s))) return r;
+  c->unet_B = B; c->unet_train = train; c->unet_seed = seed;
+  return PU_OK;
+}
+// expects feat.g filled; clears/uses the gradient flags of all U-Net tensors
+template <typename T>
+static int unet_backward(pu_ctx* c, hipStream_t s) {
+  int r; const int B = c->unet_B, train = c->unet_train; const uint64_t seed = c->unet_seed;
+  if (B <= 0) FAIL(PU_ERR_STATE, "U-Net backward without a forward");
+  std::fill(c->flags.begin(), c->flags.end(), 0);
+  Act& last = c->dec.back().out;
+  if ((r = conv_wgrad<T>(c, c->out_conv, c->feat.g, c->out_a.v, B, s))) return r;
+  if ((r = conv_bgrad<T>(c, c->feat.g, B, G(c, c->out_conv.b_off), nullptr, s))) return r;
+  if ((r = conv_dgrad<T>(c, c->out_conv, c->feat.g, c->out_a.g, B, 0, s))) return r;
+  if ((r = gn_bwd<T>(c, c->out_norm, last.v, c->out_a.v, c->out_a.g, last.g, take_acc(c, last), B, train, seed, s))) return r;
+  for (int j = (int)c->dec.size() - 1; j >= 0; --j) if ((r = block_bwd<T>(c, c->dec[j], B, train, seed, true, s))) return r;
+  for (int i = (int)c->enc.size() - 1; i >= 0; --i) if ((r = block_bwd<T>(c, c->enc[i], B, train, seed, i > 0, s))) return r;
+  return PU_OK;
+}
+
+// ------------------------------------------------------------------ Gaussian encoders
+template <typename T>
+static int gauss_forward(pu_ctx* c, GaussNet& g, int B, hipStream_t s) {
+  int r;
+  for (size_t i = 0; i < g.convs.size(); ++i) {
+    if (g.pool_before[i]) CKH(launch_maxpool<T>(with_b(g.outs[i - 1].v, B), with_b(g.ins[i].v, B), s));
+    if ((r = conv_fwd<T>(c, g.convs[i], g.ins[i].v, g.outs[i].v, B, true, nullptr, 0, s))) return r;
+  }
+  const int L = c->cfg.latent_dim;
+  CKH(launch_heads_fwd<T>(with_b(g.outs.back().v, B), P(c, g.wmu), P(c, g.bmu), P(c, g.wls), P(c, g.bls), L, g.hbuf, g.mu, g.ls, s));
+  g.lastB = B;
+  return PU_OK;
+}
+// expects g.dmu / g.dls filled
+template <typename T>
+static int gauss_backward(pu_ctx* c, GaussNet& g, hipStream_t s) {
+  int r; const int B = g.lastB, L = c->cfg.latent_dim;
+  if (B <= 0) FAIL(PU_ERR_STATE, "Gaussian-encoder backward without a forward");
+  TV lastg = with_b(g.outs.back().g, B);
+  CKH(launch_heads_bwd<T>(with_b(g.outs.back().v, B), lastg, g.hbuf, P(c, g.wmu), P(c, g.wls), g.dmu, g.dls, L,
+                          G(c, g.wmu), G(c, g.bmu), G(c, g.wls), G(c, g.bls), s));
+  for (int i = (int)g.convs.size() - 1; i >= 0; --i) {
+    TV dy = with_b(g.outs[i].g, B);
+    CKH(launch_relu_bwd<T>(with_b(g.outs[i].v, B), dy, s));
+    if ((r = conv_wgrad<T>(c, g.convs[i], g.outs[i].g, g.ins[i].v, B, s))) return r;
+    if ((r = conv_bgrad<T>(c, g.outs[i].g, B, G(c, g.convs[i].b_off), nullptr, s))) return r;
+    if (i == 0) break;
+    if ((r = conv_dgrad<T>(c, g.convs[i], g.outs[i].g, g.ins[i].g, B, 0, s))) return r;
+    if (g.pool_before[i]) CKH(launch_maxpool_bwd<T>(with_b(g.outs[i - 1].v, B), with_b(g.ins[i].g, B), with_b(g.outs[i - 1].g, B), s));
+    // else ins[i] aliases outs[i-1] (same Act): gradient already in place
+  }
+  return PU_OK;
+}
+
+static FcombArgs fcomb_args(pu_ctx* c, TV feat, int bcast, const float* z, int B, int M, float* out) {
+  FcombArgs a; memset(&a, 0, sizeof a);
+  a.feat = feat; a.bcast = bcast; a.z = z;
+  a.w0 = P(c, c->fc_w0); a.b0 = P(c, c->fc_b0); a.w1 = P(c, c->fc_w1); a.b1 = P(c, c->fc_b1); a.w2 = P(c, c->fc_w2); a.b2 = P(c, c->fc_b2);
+  a.F = c->cfg.num_filters[0]; a.L = c->cfg.latent_dim; a.Cout = c->cfg.num_classes; a.B = B; a.M = M; a.out = out;
+  return a;
+}
+
+// ------------------------------------------------------------------ C ABI
+extern "C" {
+
+int pu_abi_version(void) { return PU_ABI; }
+const char* pu_last_error(pu_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
+
+int pu_create(const pu_config* cfg, int device, pu_ctx** out) {
+  if (!cfg || !out) { g_create_err = "null argument"; return PU_ERR_INVALID; }
+  pu_ctx* c = new pu_ctx();
+  c->cfg = *cfg; c->device = device; c->dt = cfg->dtype;
+  auto bail = [&](int code) { g_create_err = c->err; delete c; return code; };
+  if (cfg->dtype < 0 || cfg->dtype > 2) { c->err = "bad dtype"; return bail(PU_ERR_INVALID); }
+  c->esz = cfg->dtype == PU_F32 ? 4 : 2;
+  if (cfg->depth < 1 || cfg->depth > PU_MAX_LEVELS || cfg->max_batch < 1 || cfg->max_members < 1 || cfg->latent_dim < 1 || cfg->latent_dim > 64) {
+    c->err = "bad depth/max_batch/max_members/latent_dim"; return bail(PU_ERR_INVALID);
+  }
+  const int div = 1 << (cfg->depth - 1);
+  if (cfg->H % div || cfg->W % div || (cfg->H / div) % 8 || (cfg->W / div) % 8) {
+    c->err = "H, W must be divisible by 2^(depth-1) with the deepest level a multiple of 8 (networks.py concat constraint + 8x8 MFMA pixel tile)";
+    return bail(PU_ERR_INVALID);
+  }
+  if (cfg->dropout_p < 0.f || cfg->dropout_p >= 1.f) { c->err = "bad dropout_p"; return bail(PU_ERR_INVALID); }
+  c->planning = true;
+  int r = build_plan(c);
+  if (r != PU_OK) return bail(r);
+  hipError_t e = hipSetDevice(device);
+  if (e != hipSuccess) { c->err = std::string("hipSetDevice: ") + hipGetErrorString(e); return bail(PU_ERR_HIP); }
+  c->arena_size = c->arena_used + 4096;
+  if ((e = hipMalloc(&c->arena, c->arena_size)) != hipSuccess) { c->err = std::string("hipMalloc(arena): ") + hipGetErrorString(e); return bail(PU_ERR_NOMEM); }
+  if ((e = hipMemset(c->arena, 0, c->arena_size)) != hipSuccess) { c->err = "hipMemset(arena)"; (void)hipFree(c->arena); return bail(PU_ERR_HIP); }
+  c->planning = false;
+  r = build_plan(c);                                      // second pass: identical walk, real pointers
+  if (r != PU_OK) { (void)hipFree(c->arena); return bail(r); }
+  if ((e = hipMalloc(&c->packed, (size_t)c->packed_elems * c->esz + 256)) != hipSuccess) { c->err = "hipMalloc(packed)"; (void)hipFree(c->arena); return bail(PU_ERR_NOMEM); }
+  if ((e = hipMalloc(&c->descs_dev, c->descs.size() * sizeof(PackDesc))) != hipSuccess) { c->err = "hipMalloc(descs)"; (void)hipFree(c->arena); (void)hipFree(c->packed); return bail(PU_ERR_NOMEM); }
+  if ((e = hipMemcpy(c->descs_dev, c->descs.data(), c->descs.size() * sizeof(PackDesc), hipMemcpyHostToDevice)) != hipSuccess) {
+    c->err = "hipMemcpy(descs)"; (void)hipFree(c->arena); (void)hipFree(c->packed); (void)hipFree(c->descs_dev); return bail(PU_ERR_HIP);
+  }
+  *out = c;
+  return PU_OK;
+}
+
+int pu_destroy(pu_ctx* c) {
+  if (!c) return PU_OK;
+  if (c->arena) (void)(void)hipFree(c->arena);
+  if (c->packed) (void)(void)hipFree(c->packed);
+  if (c->descs_dev) (void)(void)hipFree(c->descs_dev);
+  delete c;
+  return PU_OK;
+}
+
+int pu_param_table(pu_ctx* c, const pu_param_desc** out, int* n) {
+  if (!c || !out || !n) return PU_ERR_INVALID;
+  *out = c->table.data(); *n = (int)c->table.size();
+  return PU_OK;
+}
+int64_t pu_param_count(pu_ctx* c) { return c ? c->nparams : -1; }
+int64_t pu_workspace_bytes(pu_ctx* c) { return c ? (int64_t)(c->arena_size + (size_t)c->packed_elems * c->esz) : -1; }
+
+int pu_bind_params(pu_ctx* c, float* p, float* g) {
+  if (!c || !p) return PU_ERR_INVALID;
+  c->params = p; c->grads = g; c->packed_valid = false;
+  return PU_OK;
+}
+int pu_params_changed(pu_ctx* c) { if (!c) return PU_ERR_INVALID; c->packed_valid = false; return PU_OK; }
+
+double pu_elbo_fwd_flops(pu_ctx* c, int B, int M) {
+  if (!c) return 0;
+  const pu_config& cf = c->cfg;
+  double f = 0;
+  auto conv = [&](const ConvL& L, const TV& out) { f += 2.0 * out.H * out.W * (double)L.cout * L.cin * L.ks * L.ks; };
+  auto blk = [&](const Block& b) { conv(b.conv0, b.is_block ? b.c0.v : b.out.v); if (b.is_block) { conv(b.conv1, b.out.v); if (b.skip == SK_CONV) conv(b.skipc, b.out.v); } };
+  for (auto& b : c->enc) blk(b);
+  for (auto& b : c->dec) blk(b);
+  conv(c->out_conv, c->feat.v);
+  for (GaussNet* g : {&c->prior, &c->post}) {
+    for (size_t i = 0; i < g->convs.size(); ++i) conv(g->convs[i], g->outs[i].v);
+    f += 2.0 * 2 * cf.latent_dim * cf.num_filters[cf.depth - 1];
+  }
+  const double F = cf.num_filters[0], HW = (double)cf.H * cf.W;
+  f += (double)M * 2.0 * HW * (F * (F + cf.latent_dim) + F * F + F * cf.num_classes);
+  return f * B;
+}
+
+static int check_B(pu_ctx* c, int B) {
+  if (B < 1 || B > c->cfg.max_batch) FAIL(PU_ERR_INVALID, "batch %d outside [1, max_batch=%d]", B, c->cfg.max_batch);
+  return PU_OK;
+}
+
+int pu_unet_fwd(pu_ctx* c, const float* x, float* feat, int B, int train, uint64_t seed, void* stream) {
+  if (!c || !x) return PU_ERR_INVALID;
+  int r; if ((r = check_B(c, B))) return r;
+  hipStream_t s = (hipStream_t)stream;
+  if ((r = ensure_packed(c, s))) return r;
+  return dispatch(c, [&](auto t) -> int {
+    typedef decltype(t) T;
+    const long HW = (long)c->cfg.H * c->cfg.W;
+    CKH(launch_nchw_to_nhwc<T>(x, (long)c->cfg.input_channels * HW, c->cfg.input_channels, nullptr, 0, with_b(c->x_in.v, B), s));
+    int q = unet_forward<T>(c, B, train, seed, s); if (q) return q;
+    if (feat) CKH(launch_nhwc_to_nchw<T>(with_b(c->feat.v, B), c->cfg.num_filters[0], feat, 0, s));
+    return PU_OK;
+  });
+}
+int pu_unet_bwd(pu_ctx* c, const float* dfeat, void* stream) {
+  if (!c || !dfeat) return PU_ERR_INVALID;
+  if (!c->grads) FAIL(PU_ERR_STATE, "no gradient buffer bound");
+  hipStream_t s = (hipStream_t)stream;
+  return dispatch(c, [&](auto t) -> int {
+    typedef decltype(t) T;
+    const int B = c->unet_B; if (B <= 0) FAIL(PU_ERR_STATE, "pu_unet_bwd without pu_unet_fwd");
+    const int F = c->cfg.num_filters[0]; const long HW = (long)c->cfg.H * c->cfg.W;
+    CKH(launch_nchw_to_nhwc<T>(dfeat, (long)F * HW, F, nullptr, 0, with_b(c->feat.g, B), s));
+    return unet_backward<T>(c, s);
+  });
+}
+
+static int gauss_input(pu_ctx* c, int which, const float* x, const float* target, int B, hipStream_t s) {
+  return dispatch(c, [&](auto t) -> int {
+    typedef decltype(t) T;
+    const long HW = (long)c->cfg.H * c->cfg.W; const int ci = c->cfg.input_channels;
+    if (which == PU_PRIOR) CKH(launch_nchw_to_nhwc<T>(x, (long)ci * HW, ci, nullptr, 0, with_b(c->x_in.v, B), s));
+    else CKH(launch_nchw_to_nhwc<T>(x, (long)ci * HW, ci, target, c->cfg.num_classes, with_b(c->xy_in.v, B), s));
+    return PU_OK;
+  });
+}
+
+int pu_gauss_fwd(pu_ctx* c, int which, const float* x, const float* target, float* mu, float* ls, int B, void* stream) {
+  if (!c || !x || (which == PU_POSTERIOR && !target)) return PU_ERR_INVALID;
+  int r; if ((r = check_B(c, B))) return r;
+  hipStream_t s = (hipStream_t)stream;
+  if ((r = ensure_packed(c, s))) return r;
+  if ((r = gauss_input(c, which, x, target, B, s))) return r;
+  GaussNet& g = which == PU_PRIOR ? c->prior : c->post;
+  r = dispatch(c, [&](auto t) -> int { typedef decltype(t) T; return gauss_forward<T>(c, g, B, s); });
+  if (r) return r;
+  const size_t n = (size_t)B * c->cfg.latent_dim * sizeof(float);
+  if (mu) CKH(hipMemcpyAsync(mu, g.mu, n, hipMemcpyDeviceToDevice, s));
+  if (ls) CKH(hipMemcpyAsync(ls, g.ls, n, hipMemcpyDeviceToDevice, s));
+  return PU_OK;
+}
+int pu_gauss_bwd(pu_ctx* c, int which, const float* dmu, const float* dls, void* stream) {
+  if (!c || !dmu || !dls) return PU_ERR_INVALID;
+  if (!c->grads) FAIL(PU_ERR_STATE, "no gradient buffer bound");
+  hipStream_t s = (hipStream_t)stream;
+  GaussNet& g = which == PU_PRIOR ? c->prior : c->post;
+  if (g.lastB <= 0) FAIL(PU_ERR_STATE, "pu_gauss_bwd without pu_gauss_fwd");
+  const size_t n = (size_t)g.lastB * c->cfg.latent_dim * sizeof(float);
+  CKH(hipMemcpyAsync(g.dmu, dmu, n, hipMemcpyDeviceToDevice, s));
+  CKH(hipMemcpyAsync(g.dls, dls, n, hipMemcpyDeviceToDevice, s));
+  return dispatch(c, [&](auto t) -> int { typedef decltype(t) T; return gauss_backward<T>(c, g, s); });
+}
+
+int pu_fcomb_fwd(pu_ctx* c, const float* feat, int64_t bstride, const float* z, float* out, int B, void* stream) {
+  if (!c || !feat || !z || !out) return PU_ERR_INVALID;
+  int r; if ((r = check_B(c, B))) return r;
+  if (!c->params) FAIL(PU_ERR_STATE, "pu_bind_params has not been called");
+  hipStream_t s = (hipStream_t)stream;
+  const int F = c->cfg.num_filters[0], L = c->cfg.latent_dim; const long HW = (long)c->cfg.H * c->cfg.W;
+  const int bcast = bstride == 0 ? 1 : 0;
+  if (!bcast && bstride != (int64_t)F * HW) FAIL(PU_ERR_INVALID, "feature batch stride must be 0 or F0*H*W");
+  CKH(hipMemcpyAsync(c->fc_z, z, (size_t)B * L * sizeof(float), hipMemcpyDeviceToDevice, s));
+  c->fc_B = B; c->fc_bcast = bcast;
+  return dispatch(c, [&](auto t) -> int {
+    typedef decltype(t) T;
+    TV fv = with_b(c->fc_feat.v, bcast ? 1 : B);
+    CKH(launch_nchw_to_nhwc<T>(feat, (long)F * HW, F, nullptr, 0, fv, s));
+    FcombArgs a = fcomb_args(c, fv, bcast, c->fc_z, B, 1, out);
+    CKH(launch_fcomb_fwd<T>(a, s));
+    return PU_OK;
+  });
+}
+int pu_fcomb_bwd(pu_ctx* c, const float* dout, float* dfeat, float* dz, void* stream) {
+  if (!c || !dout) return PU_ERR_INVALID;
+  if (!c->grads) FAIL(PU_ERR_STATE, "no gradient buffer bound");
+  if (c->fc_B <= 0) FAIL(PU_ERR_STATE, "pu_fcomb_bwd without pu_fcomb_fwd");
+  hipStream_t s = (hipStream_t)stream;
+  const int B = c->fc_B, F = c->cfg.num_filters[0];
+  return dispatch(c, [&](auto t) -> int {
+    typedef decltype(t) T;
+    TV fv = with_b(c->fc_feat.v, c->fc_bcast ? 1 : B);
+    FcombBwdArgs a; memset(&a, 0, sizeof a);
+    a.f = fcomb_args(c, fv, c->fc_bcast, c->fc_z, B, 1, nullptr);
+    a.dout = dout; a.dfeat = with_b(c->fc_feat.g, B); a.dfeat_accumulate = 0; if (!dfeat) a.dfeat.p = nullptr;
+    a.dz = dz;
+    a.dw0 = G(c, c->fc_w0); a.db0 = G(c, c->fc_b0); a.dw1 = G(c, c->fc_w1); a.db1 = G(c, c->fc_b1); a.dw2 = G(c, c->fc_w2); a.db2 = G(c, c->fc_b2);
+    CKH(launch_fcomb_bwd<T>(a, s));
+    if (dfeat) CKH(launch_nhwc_to_nchw<T>(with_b(c->fc_feat.g, B), F, dfeat, 0, s));
+    return PU_OK;
+  });
+}
+
+int pu_elbo_fwd_bwd(pu_ctx* c, const float* x, const float* target, const float* eps, int B, int M, int recon_kind,
+                    float beta0, float beta1, float beta2, float alpha, int train, uint64_t seed, int with_backward,
+                    float* out_scalars, float* out_kl, void* stream) {
+  if (!c || !x || !target || !eps) return PU_ERR_INVALID;
+  int r; if ((r = check_B(c, B))) return r;
+  if (M < 1 || M > c->cfg.max_members) FAIL(PU_ERR_INVALID, "M=%d outside [1, max_members=%d]", M, c->cfg.max_members);
+  if (recon_kind == PU_RECON_AFCRPS && M < 2) FAIL(PU_ERR_INVALID, "M must be at least 2 to compute afCRPS but got M=%d", M);
+  if (recon_kind != PU_RECON_AFCRPS && recon_kind != PU_RECON_L1) FAIL(PU_ERR_INVALID, "unknown recon kind %d", recon_kind);
+  if (with_backward && !c->grads) FAIL(PU_ERR_STATE, "no gradient buffer bound");
+  hipStream_t s = (hipStream_t)stream;
+  if ((r = ensure_packed(c, s))) return r;
+  const pu_config& cf = c->cfg;
+  const long HW = (long)cf.H * cf.W; const int L = cf.latent_dim, Co = cf.num_classes, ci = cf.input_channels;
+  const bool l1 = recon_kind == PU_RECON_L1;
+  const int Mf = l1 ? 1 : M;
+  return dispatch(c, [&](auto t) -> int {
+    typedef decltype(t) T;
+    int q;
+    CKH(launch_nchw_to_nhwc<T>(x, (long)ci * HW, ci, nullptr, 0, with_b(c->x_in.v, B), s));
+    CKH(launch_nchw_to_nhwc<T>(x, (long)ci * HW, ci, target, Co, with_b(c->xy_in.v, B), s));
+    if ((q = unet_forward<T>(c, B, train, seed, s))) return q;
+    if ((q = gauss_forward<T>(c, c->prior, B, s))) return q;
+    if ((q = gauss_forward<T>(c, c->post, B, s))) return q;
+    CKH(hipMemsetAsync(c->scal, 0, PU_NUM_SCALARS * sizeof(float), s));
+    LatentArgs la; memset(&la, 0, sizeof la);
+    la.mu_q = c->post.mu; la.ls_q = c->post.ls; la.mu_p = c->prior.mu; la.ls_p = c->prior.ls; la.eps = eps; la.z = c->z;
+    la.kl = c->kl; la.kl2 = c->kl2; la.scalars = c->scal; la.B = B; la.L = L; la.M = Mf;
+    CKH(launch_latent_fwd(la, s));
+    FcombArgs fa = fcomb_args(c, with_b(c->feat.v, B), 0, c->z, B, Mf, c->preds);
+    CKH(launch_fcomb_fwd<T>(fa, s));
+    CKH(launch_recon(recon_kind, c->preds, target, with_backward ? c->dpreds : nullptr, c->scal, B, Mf, Co, HW, alpha, beta0, s));
+    CKH(launch_finish_scalars(c->scal, beta0, beta1, beta2, l1 ? 1 : 0, s));
+    if (out_scalars) CKH(hipMemcpyAsync(out_scalars, c->scal, PU_NUM_SCALARS * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (out_kl) CKH(hipMemcpyAsync(out_kl, c->kl, (size_t)B * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (!with_backward) return PU_OK;
+    // ---------------- backward
+    CKH(hipMemsetAsync(c->grads, 0, (size_t)c->nparams * sizeof(float), s));
+    FcombBwdArgs fb; memset(&fb, 0, sizeof fb);
+    fb.f = fa; fb.dout = c->dpreds; fb.dfeat = with_b(c->feat.g, B); fb.dfeat_accumulate = 0; fb.dz = c->dz;
+    fb.dw0 = G(c, c->fc_w0); fb.db0 = G(c, c->fc_b0); fb.dw1 = G(c, c->fc_w1); fb.db1 = G(c, c->fc_b1); fb.dw2 = G(c, c->fc_w2); fb.db2 = G(c, c->fc_b2);
+    CKH(launch_fcomb_bwd<T>(fb, s));
+    LatentBwdArgs lb; memset(&lb, 0, sizeof lb);
+    lb.f = la; lb.dz = c->dz; lb.beta1 = beta1; lb.beta2 = l1 ? beta2 : 0.f;
+    lb.dmu_q = c->post.dmu; lb.dls_q = c->post.dls; lb.dmu_p = c->prior.dmu; lb.dls_p = c->prior.dls;
+    CKH(launch_latent_bwd(lb, s));
+    if ((q = gauss_backward<T>(c, c->post, s))) return q;
+    if ((q = gauss_backward<T>(c, c->prior, s))) return q;
+    return unet_backward<T>(c, s);
+  });
+}
+
+__global__ void export_mu_sigma_kernel(const float* mu, const float* ls, float* omu, float* osig, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { if (omu) omu[i] = mu[i]; if (osig) osig[i] = expf(ls[i]) + 1e-7f; }
+}
+
+int pu_sample(pu_ctx* c, const float* x, const float* target, const float* eps, int B, int n, float* out, float* mu, float* sigma, void* stream) {
+  if (!c || !x || !eps || !out) return PU_ERR_INVALID;
+  int r; if ((r = check_B(c, B))) return r;
+  if (n < 1 || n > c->cfg.max_members) FAIL(PU_ERR_INVALID, "n=%d outside [1, max_members=%d]", n, c->cfg.max_members);
+  hipStream_t s = (hipStream_t)stream;
+  if ((r = ensure_packed(c, s))) return r;
+  const pu_config& cf = c->cfg;
+  const long HW = (long)cf.H * cf.W; const int L = cf.latent_dim, ci = cf.input_channels;
+  return dispatch(c, [&](auto t) -> int {
+    typedef decltype(t) T;
+    int q;
+    CKH(launch_nchw_to_nhwc<T>(x, (long)ci * HW, ci, nullptr, 0, with_b(c->x_in.v, B), s));
+    if (target) CKH(launch_nchw_to_nhwc<T>(x, (long)ci * HW, ci, target, cf.num_classes, with_b(c->xy_in.v, B), s));
+    if ((q = unet_forward<T>(c, B, 0, 0, s))) return q;
+    GaussNet& g = target ? c->post : c->prior;
+    if ((q = gauss_forward<T>(c, g, B, s))) return q;
+    LatentArgs la; memset(&la, 0, sizeof la);
+    la.mu_q = g.mu; la.ls_q = g.ls; la.eps = eps; la.z = c->z; la.B = B; la.L = L; la.M = n;
+    CKH(launch_latent_fwd(la, s));
+    FcombArgs fa = fcomb_args(c, with_b(c->feat.v, B), 0, c->z, B, n, out);
+    CKH(launch_fcomb_fwd<T>(fa, s));
+    if (mu || sigma) hipLaunchKernelGGL(export_mu_sigma_kernel, dim3(cdiv((long)B * L, 256)), dim3(256), 0, s, g.mu, g.ls, mu, sigma, B * L);
+    return PU_OK;
+  });
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------ single-op test entry points
+#define CK0(expr) do { hipError_t _e = (expr); if (_e != hipSuccess) { g_create_err = std::string(#expr) + ": " + hipGetErrorString(_e); rc = PU_ERR_HIP; goto done; } } while (0)
+
+template <typename T>
+static int op_conv_t(int mode, int ks, int relu, int B, int Cin, int Cout, int H, int W, const float* x, const float* w, const float* bias,
+                     const float* dy, float* out, hipStream_t s) {
+  int rc = PU_OK;
+  const size_t esz = sizeof(T); const int taps = ks * ks;
+  const int cin_a = rup(Cin, 8), cout_a = rup(Cout, 8);
+  T *xin = nullptr, *yb = nullptr, *wp = nullptr; PackDesc* dd = nullptr; float* dwtmp = nullptr;
+  const long npix = (long)B * H * W;
+  PackDesc d; d.src_off = 0; d.dst_off = 0; d.Cout = Cout; d.Cin = Cin; d.taps = taps;
+  TV tx, ty;
+  CK0(hipMalloc(&xin, npix * cin_a * esz)); CK0(hipMalloc(&yb, npix * cout_a * esz));
+  CK0(hipMalloc(&dd, sizeof(PackDesc)));
+  tx.p = xin; tx.B = B; tx.H = H; tx.W = W; tx.C = cin_a; tx.ld = cin_a;
+  ty.p = yb; ty.B = B; ty.H = H; ty.W = W; ty.C = cout_a; ty.ld = cout_a;
+  if (mode == 0) {
+    d.rows_pk = rup(Cout, 32); d.k_pk = rup(Cin, 32); d.mode = 0;
+    CK0(hipMalloc(&wp, (size_t)d.rows_pk * taps * d.k_pk * esz));
+    CK0(hipMemcpyAsync(dd, &d, sizeof d, hipMemcpyHostToDevice, s));
+    CK0(launch_pack<T>(w, wp, dd, 1, s));
+    CK0(launch_nchw_to_nhwc<T>(x, (long)Cin * H * W, Cin, nullptr, 0, tx, s));
+    ConvArgs a; memset(&a, 0, sizeof a);
+    a.in = xin; a.in_ld = cin_a; a.Cin = cin_a; a.wpk = wp; a.cin_pk = d.k_pk; a.cout_pk = d.rows_pk; a.taps = taps; a.bias = bias;
+    a.out = yb; a.out_ld = cout_a; a.Cout = Cout; a.B = B; a.H = H; a.W = W; a.relu = relu;
+    CK0(hipMemsetAsync(yb, 0, npix * cout_a * esz, s));
+    CK0(launch_conv<T>(a, s));
+    CK0(launch_nhwc_to_nchw<T>(ty, Cout, out, 0, s));
+  } else if (mode == 1) {
+    d.rows_pk = rup(Cin, 32); d.k_pk = rup(Cout, 32); d.mode = 1;
+    CK0(hipMalloc(&wp, (size_t)d.rows_pk * taps * d.k_pk * esz));
+    CK0(hipMemcpyAsync(dd, &d, sizeof d, hipMemcpyHostToDevice, s));
+    CK0(launch_pack<T>(w, wp, dd, 1, s));
+    CK0(launch_nchw_to_nhwc<T>(dy, (long)Cout * H * W, Cout, nullptr, 0, ty, s));
+    ConvArgs a; memset(&a, 0, sizeof a);
+    a.in = yb; a.in_ld = cout_a; a.Cin = cout_a; a.wpk = wp; a.cin_pk = d.k_pk; a.cout_pk = d.rows_pk; a.taps = taps;
+    a.out = xin; a.out_ld = cin_a; a.Cout = cin_a; a.B = B; a.H = H; a.W = W;
+    CK0(launch_conv<T>(a, s));
+    CK0(launch_nhwc_to_nchw<T>(tx, Cin, out, 0, s));
+  } else {
+    CK0(launch_nchw_to_nhwc<T>(x, (long)Cin * H * W, Cin, nullptr, 0, tx, s));
+    CK0(launch_nchw_to_nhwc<T>(dy, (long)Cout * H * W, Cout, nullptr, 0, ty, s));
+    CK0(hipMemsetAsync(out, 0, (size_t)Cout * Cin * taps * sizeof(float), s));
+    WgradArgs a; memset(&a, 0, sizeof a);
+    a.dy = yb; a.dy_ld = cout_a; a.Cout = Cout; a.in = xin; a.in_ld = cin_a; a.Cin = Cin; a.dw = out; a.B = B; a.H = H; a.W = W; a.taps = taps;
+    CK0(launch_wgrad<T>(a, s));
+  }
+  CK0(hipStreamSynchronize(s));
+done:
+  (void)hipFree(xin); (void)hipFree(yb); (void)hipFree(wp); (void)hipFree(dd); (void)hipFree(dwtmp);
+  return rc;
+}
+
+extern "C" int pu_op_conv(int dtype, int mode, int ks, int relu, int B, int Cin, int Cout, int H, int W, const float* x, const float* w,
+               const float* bias, const float* dy, float* out, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if ((ks != 1 && ks != 3) || mode < 0 || mode > 2) return PU_ERR_INVALID;
+  if (dtype == PU_F32) return op_conv_t<float>(mode, ks, relu, B, Cin, Cout, H, W, x, w, bias, dy, out, s);
+  if (dtype == PU_F16) return op_conv_t<f16>(mode, ks, relu, B, Cin, Cout, H, W, x, w, bias, dy, out, s);
+  if (dtype == PU_BF16) return op_conv_t<bf16>(mode, ks, relu, B, Cin, Cout, H, W, x, w, bias, dy, out, s);
+  return PU_ERR_INVALID;
+}
+
+template <typename T>
+static int op_gn_t(int resample, int B, int C, int H, int W, const float* x, const float* gamma, const float* beta, const float* ss, float* y,
+                   const float* dy, float* dx, float* dgamma, float* dbeta, float* dss, hipStream_t s) {
+  int rc = PU_OK;
+  const size_t esz = sizeof(T);
+  const int OH = resample == RS_DOWN ? H / 2 : (resample == RS_UP ? H * 2 : H), OW = resample == RS_DOWN ? W / 2 : (resample == RS_UP ? W * 2 : W);
+  const long nin = (long)B * H * W * C, nout = (long)B * OH * OW * C;
+  T *xb = nullptr, *yb = nullptr, *dyb = nullptr, *dxb = nullptr, *dvb = nullptr; float* ws = nullptr;
+  const int G = gn_groups(C), nchunk = gn_chunks((long)H * W);
+  const size_t nws = (size_t)B * nchunk * C * 2 * 2 + (size_t)B * G * 2 + (size_t)B * C * 2 + (size_t)B * C * 3;
+  GNArgs a; GNBwdArgs bw; TV tx, ty;
+  CK0(hipMalloc(&xb, nin * esz)); CK0(hipMalloc(&yb, nout * esz)); CK0(hipMalloc(&dyb, nout * esz)); CK0(hipMalloc(&dxb, nin * esz));
+  CK0(hipMalloc(&dvb, nin * esz)); CK0(hipMalloc(&ws, nws * sizeof(float)));
+  tx.p = xb; tx.B = B; tx.H = H; tx.W = W; tx.C = C; tx.ld = C;
+  ty.p = yb; ty.B = B; ty.H = OH; ty.W = OW; ty.C = C; ty.ld = C;
+  memset(&a, 0, sizeof a);
+  a.x = tx; a.y = ty; a.G = G; a.eps = 1e-5f; a.gamma = gamma; a.beta = beta; a.scale = ss; a.shift = ss ? ss + C : nullptr; a.resample = resample;
+  a.part = ws; a.nchunk = nchunk; a.stat = ws + (size_t)B * nchunk * C * 2; a.coef = a.stat + (size_t)B * G * 2;
+  CK0(launch_nchw_to_nhwc<T>(x, (long)C * H * W, C, nullptr, 0, tx, s));
+  CK0(launch_gn_fwd<T>(a, s));
+  CK0(launch_nhwc_to_nchw<T>(ty, C, y, 0, s));
+  if (dy) {
+    TV tdy = ty; tdy.p = dyb; TV tdx = tx; tdx.p = dxb; TV tdv = tx; tdv.p = dvb;
+    CK0(launch_nchw_to_nhwc<T>(dy, (long)C * OH * OW, C, nullptr, 0, tdy, s));
+    memset(&bw, 0, sizeof bw);
+    bw.f = a; bw.dy = tdy; bw.dv = tdv; bw.dx = tdx; bw.accumulate = 0;
+    bw.dgamma = dgamma; bw.dbeta = dbeta; bw.dscale = ss ? dss : nullptr; bw.dshift = ss ? dss + C : nullptr;
+    bw.part2 = a.coef + (size_t)B * C * 2; bw.coef2 = bw.part2 + (size_t)B * nchunk * C * 2;
+    CK0(hipMemsetAsync(dgamma, 0, C * sizeof(float), s)); CK0(hipMemsetAsync(dbeta, 0, C * sizeof(float), s));
+    if (ss) CK0(hipMemsetAsync(dss, 0, 2 * C * sizeof(float), s));
+    CK0(launch_gn_bwd<T>(bw, s));
+    CK0(launch_nhwc_to_nchw<T>(tdx, C, dx, 0, s));
+  }
+  CK0(hipStreamSynchronize(s));
+done:
+  (void)hipFree(xb); (void)hipFree(yb); (void)hipFree(dyb); (void)hipFree(dxb); (void)hipFree(dvb); (void)hipFree(ws);
+  return rc;
+}
+
+extern "C" int pu_op_gnsilu(int dtype, int resample, int B, int C, int H, int W, const float* x, const float* gamma, const float* beta,
+                 const float* ss, float* y, const float* dy, float* dx, float* dgamma, float* dbeta, float* dss, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (C % 8) return PU_ERR_INVALID;
+  if (dtype == PU_F32) return op_gn_t<float>(resample, B, C, H, W, x, gamma, beta, ss, y, dy, dx, dgamma, dbeta, dss, s);
+  if (dtype == PU_F16) return op_gn_t<f16>(resample, B, C, H, W, x, gamma, beta, ss, y, dy, dx, dgamma, dbeta, dss, s);
+  if (dtype == PU_BF16) return op_gn_t<bf16>(resample, B, C, H, W, x, gamma, beta, ss, y, dy, dx, dgamma, dbeta, dss, s);
+  return PU_ERR_INVALID;
+}

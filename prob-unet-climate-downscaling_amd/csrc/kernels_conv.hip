@@ -1,0 +1,448 @@
+// Implicit-GEMM convolution kernels for gfx950 (MFMA), NHWC activations.
+//
+//   conv_igemm : y[b,p,co] = sum_{tap,ci} in[b,p+tap,ci] * w[co,tap,ci]  (+bias, +residual, ReLU, accumulate)
+//                used for forward (networks.py:89, prob_unet.py:41,45) and, with the (flipped, transposed) packed
+//                weights, for the data gradient (aten conv backward-input).
+//   conv_wgrad : dw[co,ci,tap] += sum_{b,p} dy[b,p,co] * in[b,p+tap,ci]   (aten conv backward-weight), split over
+//                pixel tiles, fp32 atomics into the flat gradient buffer.
+//
+// GEMM orientation: D[row = cout][col = pixel] = W[cout][k] * X[k][pixel], k = (tap, cin-chunk).
+//   v_mfma_f32_32x32x16_{f16,bf16}: lane l holds A[row l&31][k 8(l>>5)..+7], B[k 8(l>>5)..+7][col l&31]
+//   v_mfma_f32_32x32x2_f32        : lane l holds A[row l&31][k l>>5],        B[k l>>5][col l&31]
+//   D: col = l&31, row = (r&3) + 8(r>>2) + 4(l>>5)            (verified on hardware, scratch/mfma_probe.hip)
+// LDS tiles are [pixel][channel] / [cout][channel] with the channel (K) axis contiguous, so one ds_read_b128 yields
+// a whole 16-bit fragment; the 3x3 halo tile is staged once per 32-channel chunk and reused by all 9 taps.
+#include "pu_kernels.h"
+
+namespace pu {
+
+// ------------------------------------------------------------------ MFMA traits
+template <typename T> struct MM;
+template <> struct MM<f16> {
+  static constexpr int KSTEP = 16;
+  static constexpr int PAD = 8;                      // LDS row pad (elements): 80-byte rows -> conflict-free b128
+  typedef f16x8 Frag;
+  __device__ static __forceinline__ Frag ld(const f16* row, int l) { return *reinterpret_cast<const f16x8*>(row + 8 * (l >> 5)); }
+  __device__ static __forceinline__ f32x16 mfma(Frag a, Frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+template <> struct MM<bf16> {
+  static constexpr int KSTEP = 16;
+  static constexpr int PAD = 8;
+  typedef bf16x8 Frag;
+  __device__ static __forceinline__ Frag ld(const bf16* row, int l) { return *reinterpret_cast<const bf16x8*>(reinterpret_cast<const uint16_t*>(row) + 8 * (l >> 5)); }
+  __device__ static __forceinline__ f32x16 mfma(Frag a, Frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct MM<float> {
+  static constexpr int KSTEP = 2;
+  static constexpr int PAD = 1;                      // 33-dword rows -> conflict-free ds_read_b32
+  typedef float Frag;
+  __device__ static __forceinline__ Frag ld(const float* row, int l) { return row[l >> 5]; }
+  __device__ static __forceinline__ f32x16 mfma(Frag a, Frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0); }
+};
+
+template <typename T> __device__ __forceinline__ void lds_store_vec(T* dst, const V16& v) { *reinterpret_cast<V16*>(dst) = v; }
+template <> __device__ __forceinline__ void lds_store_vec<float>(float* dst, const V16& v) {   // rows are 33 dwords: not 16B aligned
+  dst[0] = __uint_as_float(v.w[0]); dst[1] = __uint_as_float(v.w[1]); dst[2] = __uint_as_float(v.w[2]); dst[3] = __uint_as_float(v.w[3]);
+}
+
+template <typename T> __device__ __forceinline__ void load4(const T* p, float* o);
+template <> __device__ __forceinline__ void load4<float>(const float* p, float* o) { f32x4 v = *reinterpret_cast<const f32x4*>(p); o[0] = v[0]; o[1] = v[1]; o[2] = v[2]; o[3] = v[3]; }
+template <> __device__ __forceinline__ void load4<f16>(const f16* p, float* o) { f16x4 v = *reinterpret_cast<const f16x4*>(p); o[0] = (float)v[0]; o[1] = (float)v[1]; o[2] = (float)v[2]; o[3] = (float)v[3]; }
+template <> __device__ __forceinline__ void load4<bf16>(const bf16* p, float* o) {
+  uint2 v = *reinterpret_cast<const uint2*>(p);
+  o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u); o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+}
+template <typename T> __device__ __forceinline__ void store4(T* p, const float* o);
+template <> __device__ __forceinline__ void store4<float>(float* p, const float* o) { f32x4 v = {o[0], o[1], o[2], o[3]}; *reinterpret_cast<f32x4*>(p) = v; }
+template <> __device__ __forceinline__ void store4<f16>(f16* p, const float* o) { f16x4 v = {(f16)o[0], (f16)o[1], (f16)o[2], (f16)o[3]}; *reinterpret_cast<f16x4*>(p) = v; }
+template <> __device__ __forceinline__ void store4<bf16>(bf16* p, const float* o) {
+  uint2 v; v.x = (uint32_t)f_to_bf16(o[0]) | ((uint32_t)f_to_bf16(o[1]) << 16); v.y = (uint32_t)f_to_bf16(o[2]) | ((uint32_t)f_to_bf16(o[3]) << 16);
+  *reinterpret_cast<uint2*>(p) = v;
+}
+
+constexpr int KC = 32;     // channels staged per K chunk
+
+// ------------------------------------------------------------------ forward / dgrad implicit GEMM
+// Block = 64*WM*WN threads; pixel tile TH x TW (BM = TH*TW pixels, BM/WM per wave in 32-pixel MFMA columns);
+// cout tile BN = 32*NTN*WN.
+template <typename T, int KS, int TH, int TW, int WM, int WN, int NTN>
+__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs a) {
+  typedef MM<T> M;
+  constexpr int NT = 64 * WM * WN;
+  constexpr int BM = TH * TW;
+  constexpr int NTM = BM / (32 * WM);
+  constexpr int BN = 32 * NTN * WN;
+  constexpr int TAPS = KS * KS;
+  constexpr int PADP = KS / 2;
+  constexpr int IH = TH + 2 * PADP, IW = TW + 2 * PADP;
+  constexpr int KCP = KC + M::PAD;
+  constexpr int VEC = ET<T>::VEC;
+  constexpr int CV = KC / VEC;
+  static_assert(BM % (32 * WM) == 0, "pixel tile");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* sIn = reinterpret_cast<T*>(smem_raw);                 // [IH*IW][KCP]
+  T* sW = sIn + IH * IW * KCP;                             // [TAPS][BN][KCP]
+
+  const int tid = threadIdx.x;
+  const int l = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave % WM, wn = wave / WM;
+
+  const int tiles_x = a.W / TW, tiles_y = a.H / TH;
+  int pt = blockIdx.x;
+  const int tx0 = (pt % tiles_x) * TW; pt /= tiles_x;
+  const int ty0 = (pt % tiles_y) * TH; pt /= tiles_y;
+  const int b = pt;
+  const int n0 = blockIdx.y * BN;
+
+  const T* in = reinterpret_cast<const T*>(a.in);
+  const T* wpk = reinterpret_cast<const T*>(a.wpk);
+
+  f32x16 acc[NTN][NTM];
+#pragma unroll
+  for (int i = 0; i < NTN; ++i)
+#pragma unroll
+    for (int j = 0; j < NTM; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // per-lane LDS bases of the B (pixel) fragments, tap (0,0)
+  int pbase[NTM];
+#pragma unroll
+  for (int j = 0; j < NTM; ++j) {
+    const int m = (wm * NTM + j) * 32 + (l & 31);
+    pbase[j] = ((m / TW) * IW + (m % TW)) * KCP;
+  }
+  const int wrow = (wn * NTN * 32 + (l & 31)) * KCP;
+
+  for (int c0 = 0; c0 < a.cin_pk; c0 += KC) {
+    __syncthreads();
+    // ---- stage input halo tile (zero fill outside the image / beyond Cin)
+    for (int i = tid; i < IH * IW * CV; i += NT) {
+      const int pix = i / CV, cv = i - pix * CV;
+      const int hy = pix / IW, hx = pix - hy * IW;
+      const int gy = ty0 + hy - PADP, gx = tx0 + hx - PADP;
+      const int ci = c0 + cv * VEC;
+      V16 v = zero16();
+      if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && ci < a.Cin)
+        v = *reinterpret_cast<const V16*>(in + ((size_t)(b * a.H + gy) * a.W + gx) * a.in_ld + ci);
+      lds_store_vec<T>(sIn + pix * KCP + cv * VEC, v);
+    }
+    // ---- stage weight tile [tap][cout][KC]
+    for (int i = tid; i < BN * TAPS * CV; i += NT) {
+      const int cv = i % CV;
+      const int t = (i / CV) % TAPS;
+      const int n = i / (CV * TAPS);
+      V16 v = zero16();
+      if (n0 + n < a.cout_pk)
+        v = *reinterpret_cast<const V16*>(wpk + ((size_t)(n0 + n) * TAPS + t) * a.cin_pk + c0 + cv * VEC);
+      lds_store_vec<T>(sW + (t * BN + n) * KCP + cv * VEC, v);
+    }
+    __syncthreads();
+    int kreal = a.Cin - c0; if (kreal > KC) kreal = KC;
+    const int ksteps = (kreal + M::KSTEP - 1) / M::KSTEP;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+      const int toff = ((t / KS) * IW + (t % KS)) * KCP;
+      const T* wt = sW + t * BN * KCP + wrow;
+      for (int kk = 0; kk < ksteps; ++kk) {
+        typename M::Frag fa[NTN], fb[NTM];
+#pragma unroll
+        for (int i = 0; i < NTN; ++i) fa[i] = M::ld(wt + i * 32 * KCP + kk * M::KSTEP, l);
+#pragma unroll
+        for (int j = 0; j < NTM; ++j) fb[j] = M::ld(sIn + pbase[j] + toff + kk * M::KSTEP, l);
+#pragma unroll
+        for (int i = 0; i < NTN; ++i)
+#pragma unroll
+          for (int j = 0; j < NTM; ++j) acc[i][j] = M::mfma(fa[i], fb[j], acc[i][j]);
+      }
+    }
+  }
+
+  // ---- epilogue: lane owns pixel (col) l&31 of each pixel sub-tile and 4 consecutive couts per register quad
+  T* out = reinterpret_cast<T*>(a.out);
+  const T* res = reinterpret_cast<const T*>(a.res);
+#pragma unroll
+  for (int j = 0; j < NTM; ++j) {
+    const int m = (wm * NTM + j) * 32 + (l & 31);
+    const int gy = ty0 + m / TW, gx = tx0 + m % TW;
+    const size_t pix = (size_t)(b * a.H + gy) * a.W + gx;
+#pragma unroll
+    for (int i = 0; i < NTN; ++i) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int co = n0 + (wn * NTN + i) * 32 + 8 * q + 4 * (l >> 5);
+        if (co < a.Cout) {
+          float v[4] = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+          if (a.bias) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += a.bias[co + e];
+          }
+          if (res) {
+            float r[4]; load4<T>(res + pix * a.res_ld + co, r);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += r[e];
+          }
+          if (a.accumulate) {
+            float r[4]; load4<T>(out + pix * a.out_ld + co, r);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += r[e];
+          }
+          if (a.relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+          }
+          store4<T>(out + pix * a.out_ld + co, v);
+        }
+      }
+    }
+  }
+}
+
+template <typename T, int KS, int TH, int TW, int WM, int WN, int NTN>
+static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
+  constexpr int TAPS = KS * KS, PADP = KS / 2;
+  constexpr int IH = TH + 2 * PADP, IW = TW + 2 * PADP, KCP = KC + MM<T>::PAD, BN = 32 * NTN * WN;
+  constexpr size_t lds = (size_t)(IH * IW + TAPS * BN) * KCP * sizeof(T);
+  auto kern = conv_igemm_kernel<T, KS, TH, TW, WM, WN, NTN>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  dim3 grid((unsigned)((a.W / TW) * (a.H / TH) * a.B), (unsigned)cdiv(a.Cout, BN));
+  hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, a);
+  return hipGetLastError();
+}
+
+template <typename T, int KS>
+static hipError_t launch_ks(const ConvArgs& a, hipStream_t s) {
+  const bool narrow = a.Cout <= 32;
+  if (a.W % 32 == 0 && a.H % 8 == 0)
+    return narrow ? launch_cfg<T, KS, 8, 32, 4, 1, 1>(a, s) : launch_cfg<T, KS, 8, 32, 4, 1, 2>(a, s);
+  if (a.W % 16 == 0 && a.H % 16 == 0)
+    return narrow ? launch_cfg<T, KS, 16, 16, 4, 1, 1>(a, s) : launch_cfg<T, KS, 16, 16, 4, 1, 2>(a, s);
+  if (a.W % 8 == 0 && a.H % 8 == 0)
+    return launch_cfg<T, KS, 8, 8, 1, 2, 1>(a, s);
+  return hipErrorInvalidValue;
+}
+
+template <typename T>
+hipError_t launch_conv(const ConvArgs& a, hipStream_t s) {
+  if (a.taps == 9) return launch_ks<T, 3>(a, s);
+  if (a.taps == 1) return launch_ks<T, 1>(a, s);
+  return hipErrorInvalidValue;
+}
+template hipError_t launch_conv<float>(const ConvArgs&, hipStream_t);
+template hipError_t launch_conv<f16>(const ConvArgs&, hipStream_t);
+template hipError_t launch_conv<bf16>(const ConvArgs&, hipStream_t);
+
+// ------------------------------------------------------------------ weight gradient
+// D[row = cout][col = cin] per tap, K = pixels. Operands are read from [pixel][channel] LDS tiles:
+//   16-bit: ds_read_b64_tr_b16 (hardware transposed read: lane i of a 16-lane group receives column i of a
+//           4-row x 16-column block; verified in scratch/mfma_probe.hip), two reads per 8-element fragment.
+//   fp32  : plain ds_read_b32 (the 32x32x2 fragment is one element per lane).
+template <typename T> struct WG;
+template <> struct WG<float> {
+  static constexpr int DPAD = 1, APAD = 1;
+};
+template <> struct WG<f16> { static constexpr int DPAD = 32, APAD = 0; };   // row strides 192 B / 64 B: == 64 (mod 256)
+template <> struct WG<bf16> { static constexpr int DPAD = 32, APAD = 0; };
+
+__device__ __forceinline__ uint64_t ds_read_tr16(const void* lds_ptr) {
+  uint64_t v;
+  const uint32_t addr = (uint32_t)(uintptr_t)lds_ptr;
+  asm volatile("ds_read_b64_tr_b16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr) : "memory");
+  return v;
+}
+
+constexpr int WG_BCO = 64, WG_BCI = 32;
+
+template <typename T, int KS, int TH, int TW>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+  typedef MM<T> M;
+  constexpr int TAPS = KS * KS, PADP = KS / 2;
+  constexpr int BM = TH * TW;
+  constexpr int IH = TH + 2 * PADP, IW = TW + 2 * PADP;
+  constexpr int DS = WG_BCO + WG<T>::DPAD;     // dy tile row stride (elements)
+  constexpr int AS = WG_BCI + WG<T>::APAD;     // input tile row stride
+  constexpr int VEC = ET<T>::VEC;
+  constexpr int NTILE = 2 * TAPS;              // (cout sub-tile, tap) MFMA tiles per block
+  constexpr int NJ = (NTILE + 3) / 4;          // per wave
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* sDy = reinterpret_cast<T*>(smem_raw);     // [BM][DS]
+  T* sA = sDy + BM * DS;                       // [IH*IW][AS]
+
+  const int tid = threadIdx.x, l = tid & 63, wave = tid >> 6;
+  const int co0 = blockIdx.y * WG_BCO, ci0 = blockIdx.z * WG_BCI;
+  const int tiles_x = a.W / TW, tiles_y = a.H / TH;
+  const int ntiles = tiles_x * tiles_y * a.B;
+  const T* dy = reinterpret_cast<const T*>(a.dy);
+  const T* in = reinterpret_cast<const T*>(a.in);
+
+  f32x16 acc[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int pt = tile;
+    const int tx0 = (pt % tiles_x) * TW; pt /= tiles_x;
+    const int ty0 = (pt % tiles_y) * TH; pt /= tiles_y;
+    const int b = pt;
+    __syncthreads();
+    for (int i = tid; i < BM * (WG_BCO / VEC); i += 256) {
+      const int pix = i / (WG_BCO / VEC), cv = i % (WG_BCO / VEC);
+      const int gy = ty0 + pix / TW, gx = tx0 + pix % TW;
+      const int co = co0 + cv * VEC;
+      V16 v = zero16();
+      if (co < a.Cout) v = *reinterpret_cast<const V16*>(dy + ((size_t)(b * a.H + gy) * a.W + gx) * a.dy_ld + co);
+      lds_store_vec<T>(sDy + pix * DS + cv * VEC, v);
+    }
+    for (int i = tid; i < IH * IW * (WG_BCI / VEC); i += 256) {
+      const int pix = i / (WG_BCI / VEC), cv = i % (WG_BCI / VEC);
+      const int hy = pix / IW, hx = pix % IW;
+      const int gy = ty0 + hy - PADP, gx = tx0 + hx - PADP;
+      const int ci = ci0 + cv * VEC;
+      V16 v = zero16();
+      if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && ci < a.Cin)
+        v = *reinterpret_cast<const V16*>(in + ((size_t)(b * a.H + gy) * a.W + gx) * a.in_ld + ci);
+      lds_store_vec<T>(sA + pix * AS + cv * VEC, v);
+    }
+    __syncthreads();
+
+    for (int kk = 0; kk < BM / M::KSTEP; ++kk) {
+      if constexpr (sizeof(T) == 2) {
+        // lane roles for the transposed reads
+        const int g = l >> 4, h = l >> 5, q = (l & 15) >> 2, p = l & 3;
+        const int cb = 16 * (g & 1) + 4 * p;
+        const int m0 = kk * 16 + 8 * h + q, m1 = m0 + 4;           // pixel rows supplied by this lane (two reads)
+        union { uint64_t u[2]; typename M::Frag f; } fa[2];
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          fa[ct].u[0] = ds_read_tr16(sDy + m0 * DS + ct * 32 + cb);
+          fa[ct].u[1] = ds_read_tr16(sDy + m1 * DS + ct * 32 + cb);
+        }
+        const int h0 = (m0 / TW) * IW + (m0 % TW), h1 = (m1 / TW) * IW + (m1 % TW);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int tl = wave + 4 * j;
+          if (tl < NTILE) {
+            const int ct = tl & 1, t = tl >> 1;
+            const int toff = (t / KS) * IW + (t % KS);
+            union { uint64_t u[2]; typename M::Frag f; } fb;
+            fb.u[0] = ds_read_tr16(sA + (h0 + toff) * AS + cb);
+            fb.u[1] = ds_read_tr16(sA + (h1 + toff) * AS + cb);
+            acc[j] = M::mfma(ct ? fa[1].f : fa[0].f, fb.f, acc[j]);
+          }
+        }
+      } else {
+        const int m = kk * 2 + (l >> 5);
+        const int hh = (m / TW) * IW + (m % TW);
+        const float a0 = reinterpret_cast<const float*>(sDy)[m * DS + (l & 31)];
+        const float a1 = reinterpret_cast<const float*>(sDy)[m * DS + 32 + (l & 31)];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int tl = wave + 4 * j;
+          if (tl < NTILE) {
+            const int ct = tl & 1, t = tl >> 1;
+            const int toff = (t / KS) * IW + (t % KS);
+            const float bv = reinterpret_cast<const float*>(sA)[(hh + toff) * AS + (l & 31)];
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ct ? a1 : a0, bv, acc[j], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+  // ---- flush: atomics into the fp32 gradient in the reference layout [Cout][Cin][KS][KS]
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int tl = wave + 4 * j;
+    if (tl < NTILE) {
+      const int ct = tl & 1, t = tl >> 1;
+      const int ci = ci0 + (l & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        if (co < a.Cout && ci < a.Cin) atomicAdd(a.dw + ((size_t)co * a.Cin + ci) * TAPS + t, acc[j][r]);
+      }
+    }
+  }
+}
+
+template <typename T, int KS, int TH, int TW>
+static hipError_t launch_wg(const WgradArgs& a, hipStream_t s) {
+  constexpr int PADP = KS / 2, BM = TH * TW, IH = TH + 2 * PADP, IW = TW + 2 * PADP;
+  constexpr size_t lds = ((size_t)BM * (WG_BCO + WG<T>::DPAD) + (size_t)IH * IW * (WG_BCI + WG<T>::APAD)) * sizeof(T);
+  auto kern = conv_wgrad_kernel<T, KS, TH, TW>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  const int ntiles = (a.W / TW) * (a.H / TH) * a.B;
+  const int gy = cdiv(a.Cout, WG_BCO), gz = cdiv(a.Cin, WG_BCI);
+  int split = cdiv(1024, gy * gz);                       // ~4 blocks per CU
+  if (split > ntiles) split = ntiles;
+  if (split < 1) split = 1;
+  hipLaunchKernelGGL(kern, dim3(split, gy, gz), dim3(256), lds, s, a);
+  return hipGetLastError();
+}
+
+template <typename T, int KS>
+static hipError_t launch_wg_ks(const WgradArgs& a, hipStream_t s) {
+  if (a.W % 32 == 0 && a.H % 4 == 0) return launch_wg<T, KS, 4, 32>(a, s);
+  if (a.W % 16 == 0 && a.H % 8 == 0) return launch_wg<T, KS, 8, 16>(a, s);
+  if (a.W % 8 == 0 && a.H % 8 == 0) return launch_wg<T, KS, 8, 8>(a, s);
+  return hipErrorInvalidValue;
+}
+
+template <typename T>
+hipError_t launch_wgrad(const WgradArgs& a, hipStream_t s) {
+  if (a.taps == 9) return launch_wg_ks<T, 3>(a, s);
+  if (a.taps == 1) return launch_wg_ks<T, 1>(a, s);
+  return hipErrorInvalidValue;
+}
+template hipError_t launch_wgrad<float>(const WgradArgs&, hipStream_t);
+template hipError_t launch_wgrad<f16>(const WgradArgs&, hipStream_t);
+template hipError_t launch_wgrad<bf16>(const WgradArgs&, hipStream_t);
+
+// ------------------------------------------------------------------ weight packing (fp32 master -> T, K-contiguous)
+// mode 0 (forward):  dst[(co*taps + t)*kpk + ci]          = w[co][ci][t]
+// mode 1 (dgrad)  :  dst[(ci*taps + t)*kpk + co]          = w[co][ci][taps-1-t]     (roles swapped, taps flipped)
+template <typename T>
+__global__ void pack_weights_kernel(const float* __restrict__ params, T* __restrict__ packed, const PackDesc* __restrict__ descs) {
+  const PackDesc d = descs[blockIdx.y];
+  const long total = (long)d.rows_pk * d.taps * d.k_pk;
+  const float* w = params + d.src_off;
+  T* dst = packed + d.dst_off;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(i % d.k_pk);
+    const int t = (int)((i / d.k_pk) % d.taps);
+    const int r = (int)(i / ((long)d.k_pk * d.taps));
+    float v = 0.f;
+    if (d.mode == 0) {
+      if (r < d.Cout && k < d.Cin) v = w[((size_t)r * d.Cin + k) * d.taps + t];
+    } else {
+      if (r < d.Cin && k < d.Cout) v = w[((size_t)k * d.Cin + r) * d.taps + (d.taps - 1 - t)];
+    }
+    ET<T>::st(dst + i, v);
+  }
+}
+
+template <typename T>
+hipError_t launch_pack(const float* params, void* packed, const PackDesc* descs_dev, int ndesc, hipStream_t s) {
+  if (ndesc == 0) return hipSuccess;
+  hipLaunchKernelGGL(pack_weights_kernel<T>, dim3(64, ndesc), dim3(256), 0, s, params, reinterpret_cast<T*>(packed), descs_dev);
+  return hipGetLastError();
+}
+template hipError_t launch_pack<float>(const float*, void*, const PackDesc*, int, hipStream_t);
+template hipError_t launch_pack<f16>(const float*, void*, const PackDesc*, int, hipStream_t);
+template hipError_t launch_pack<bf16>(const float*, void*, const PackDesc*, int, hipStream_t);
+
+}  // namespace pu

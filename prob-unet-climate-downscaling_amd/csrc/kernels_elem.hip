@@ -1,0 +1,823 @@
+// Bandwidth-bound kernels of the Probabilistic U-Net path (NHWC activations): layout conversion, GroupNorm+SiLU
+// (+adaptive scale/shift, dropout, 2x resample) forward/backward, max-pool, ReLU backward, bias gradient,
+// Gaussian-encoder heads, latent sampling + KL, afCRPS / L1 reconstruction loss.
+// Every kernel moves 16 bytes per lane along the channel axis (contiguous in NHWC).
+#include "pu_kernels.h"
+#include "../../include/probunet.h"
+
+namespace pu {
+
+template <typename T> __device__ __forceinline__ V16 ldv(const T* p) { return *reinterpret_cast<const V16*>(p); }
+template <typename T> __device__ __forceinline__ void stv(T* p, const V16& v) { *reinterpret_cast<V16*>(p) = v; }
+
+// ------------------------------------------------------------------ layout conversion
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ s0, long bs0, int c0, const float* __restrict__ s1, int c1, TV d) {
+  constexpr int VEC = ET<T>::VEC;
+  const long HW = (long)d.H * d.W;
+  const int CV = d.C / VEC;
+  const long total = (long)d.B * CV * HW;
+  T* dst = reinterpret_cast<T*>(d.p);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long p = i % HW;
+    const int cv = (int)((i / HW) % CV);
+    const int b = (int)(i / (HW * CV));
+    float v[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const int c = cv * VEC + e;
+      float x = 0.f;
+      if (c < c0) x = s0[(long)b * bs0 + (long)c * HW + p];
+      else if (c < c0 + c1) x = s1[((long)b * c1 + (c - c0)) * HW + p];
+      v[e] = x;
+    }
+    stv<T>(dst + ((long)b * HW + p) * d.ld + cv * VEC, pack<T>(v));
+  }
+}
+template <typename T>
+hipError_t launch_nchw_to_nhwc(const float* s0, long bs0, int c0, const float* s1, int c1, TV d, hipStream_t s) {
+  const long total = (long)d.B * (d.C / ET<T>::VEC) * d.H * d.W;
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel<T>, dim3((unsigned)min((long)8192, (total + 255) / 256)), dim3(256), 0, s, s0, bs0, c0, s1, c1, d);
+  return hipGetLastError();
+}
+
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(TV src, int C, float* __restrict__ dst, int accumulate) {
+  // 32-pixel x 32-channel LDS transpose so that both sides are coalesced
+  __shared__ float tile[32][33];
+  const long HW = (long)src.H * src.W;
+  const int ntp = (int)((HW + 31) / 32), ntc = (C + 31) / 32;
+  const T* sp = reinterpret_cast<const T*>(src.p);
+  const long ntiles = (long)src.B * ntp * ntc;
+  for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const int tc = (int)(t % ntc);
+    const int tp = (int)((t / ntc) % ntp);
+    const int b = (int)(t / ((long)ntc * ntp));
+    const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;      // 256 threads: 8 rows per pass
+    __syncthreads();
+    for (int r = ly; r < 32; r += 8) {
+      const long p = (long)tp * 32 + r; const int c = tc * 32 + lx;
+      tile[r][lx] = (p < HW && c < C) ? ET<T>::ld(sp + ((long)b * HW + p) * src.ld + c) : 0.f;
+    }
+    __syncthreads();
+    for (int r = ly; r < 32; r += 8) {
+      const int c = tc * 32 + r; const long p = (long)tp * 32 + lx;
+      if (p < HW && c < C) {
+        float* q = dst + ((long)b * C + c) * HW + p;
+        *q = accumulate ? *q + tile[lx][r] : tile[lx][r];
+      }
+    }
+  }
+}
+template <typename T>
+hipError_t launch_nhwc_to_nchw(TV src, int C, float* dst, int accumulate, hipStream_t s) {
+  const long HW = (long)src.H * src.W;
+  const long ntiles = (long)src.B * ((HW + 31) / 32) * ((C + 31) / 32);
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel<T>, dim3((unsigned)min((long)16384, ntiles)), dim3(256), 0, s, src, C, dst, accumulate);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ GroupNorm + SiLU forward
+// pass 1: per (b, pixel chunk, channel) sum and sum of squares (fp32, short per-thread chains + LDS tree)
+template <typename T, bool SQ>
+__global__ __launch_bounds__(256) void chan_partial_kernel(TV x, float* __restrict__ part, int nchunk, int per_batch) {
+  constexpr int VEC = ET<T>::VEC;
+  __shared__ float buf[256 * VEC * 2];
+  const int CV = x.C / VEC;
+  const int PL = 256 / CV;                        // pixel lanes per block (CV <= 256)
+  const int tid = threadIdx.x;
+  const int cv = tid % CV, pl = tid / CV;
+  const int chunk = blockIdx.x, b = blockIdx.y;
+  const long npix = per_batch ? (long)x.H * x.W : (long)x.B * x.H * x.W;
+  const long per = (npix + nchunk - 1) / nchunk;
+  const long p0 = (long)chunk * per, p1 = min(npix, p0 + per);
+  const T* xp = reinterpret_cast<const T*>(x.p) + (per_batch ? (long)b * x.H * x.W * x.ld : 0);
+  float s1[VEC], s2[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+  if (pl < PL) {
+    for (long p = p0 + pl; p < p1; p += PL) {
+      float v[VEC]; unpack<T>(ldv<T>(xp + p * x.ld + cv * VEC), v);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) { s1[e] += v[e]; if (SQ) s2[e] += v[e] * v[e]; }
+    }
+  }
+  // buf layout [pl][c][2]
+  if (pl < PL) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { buf[(pl * x.C + cv * VEC + e) * 2] = s1[e]; buf[(pl * x.C + cv * VEC + e) * 2 + 1] = s2[e]; }
+  }
+  __syncthreads();
+  const int nout = x.C * 2;
+  for (int o = tid; o < nout; o += 256) {
+    float acc = 0.f;
+    for (int q = 0; q < PL; ++q) acc += buf[q * nout + o];
+    const long slot = per_batch ? ((long)b * nchunk + chunk) : chunk;
+    if (SQ) part[slot * nout + o] = acc;
+    else if ((o & 1) == 0) part[slot * x.C + (o >> 1)] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part, int nchunk, int C, int G, long HW, float eps,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                                          float* __restrict__ stat, float* __restrict__ coef) {
+  __shared__ double cs[1024 * 2];
+  __shared__ float gs[64];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  for (int c = tid; c < C; c += 256) {
+    double a = 0, q = 0;
+    for (int k = 0; k < nchunk; ++k) { const float* pp = part + (((long)b * nchunk + k) * C + c) * 2; a += pp[0]; q += pp[1]; }
+    cs[c * 2] = a; cs[c * 2 + 1] = q;
+  }
+  __syncthreads();
+  const int cpg = C / G;
+  if (tid < G) {
+    double a = 0, q = 0;
+    for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { a += cs[c * 2]; q += cs[c * 2 + 1]; }
+    const double n = (double)cpg * (double)HW;
+    const double mean = a / n;
+    double var = q / n - mean * mean; if (var < 0) var = 0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    gs[tid * 2] = (float)mean; gs[tid * 2 + 1] = rstd;
+    stat[((long)b * G + tid) * 2] = (float)mean; stat[((long)b * G + tid) * 2 + 1] = rstd;
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    const int g = c / cpg;
+    const float mean = gs[g * 2], rstd = gs[g * 2 + 1];
+    const float s = scale ? scale[c] : 0.f, t = shift ? shift[c] : 0.f;
+    const float A = rstd * gamma[c] * (1.f + s);
+    const float Bc = (beta[c] - mean * rstd * gamma[c]) * (1.f + s) + t;
+    coef[((long)b * C + c) * 2] = A; coef[((long)b * C + c) * 2 + 1] = Bc;
+  }
+}
+
+template <typename T, int RS>
+__global__ void gn_apply_kernel(GNArgs a) {
+  constexpr int VEC = ET<T>::VEC;
+  const int C = a.x.C, CV = C / VEC;
+  const int OH = a.y.H, OW = a.y.W;
+  const long total = (long)a.x.B * OH * OW * CV;
+  const T* xp = reinterpret_cast<const T*>(a.x.p);
+  T* yp = reinterpret_cast<T*>(a.y.p);
+  const float keep = 1.f - a.drop_p, inv_keep = a.drop_p > 0.f ? 1.f / keep : 1.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % CV);
+    long p = i / CV;
+    const int ox = (int)(p % OW); p /= OW;
+    const int oy = (int)(p % OH);
+    const int b = (int)(p / OH);
+    float A[VEC], Bc[VEC];
+    const float* cf = a.coef + ((long)b * C + cv * VEC) * 2;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { A[e] = cf[2 * e]; Bc[e] = cf[2 * e + 1]; }
+    float o[VEC];
+    if (RS == RS_DOWN) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) o[e] = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int iy = 2 * oy + (q >> 1), ix = 2 * ox + (q & 1);
+        float v[VEC]; unpack<T>(ldv<T>(xp + (((long)b * a.x.H + iy) * a.x.W + ix) * a.x.ld + cv * VEC), v);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) o[e] += 0.25f * silu_f(A[e] * v[e] + Bc[e]);
+      }
+    } else {
+      const int iy = RS == RS_UP ? oy >> 1 : oy, ix = RS == RS_UP ? ox >> 1 : ox;
+      float v[VEC]; unpack<T>(ldv<T>(xp + (((long)b * a.x.H + iy) * a.x.W + ix) * a.x.ld + cv * VEC), v);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) o[e] = silu_f(A[e] * v[e] + Bc[e]);
+      if (RS == RS_NONE && a.drop_p > 0.f) {
+        const uint64_t base = (((uint64_t)b * OH + oy) * OW + ox) * (uint64_t)C + (uint64_t)cv * VEC;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) o[e] = hash_uniform(a.drop_seed, a.drop_stream, base + e) < keep ? o[e] * inv_keep : 0.f;
+      }
+    }
+    stv<T>(yp + (((long)b * OH + oy) * OW + ox) * a.y.ld + cv * VEC, pack<T>(o));
+  }
+}
+
+static inline unsigned ew_grid(long total) { long g = (total + 255) / 256; return (unsigned)(g > 8192 ? 8192 : (g < 1 ? 1 : g)); }
+
+template <typename T>
+hipError_t launch_gn_fwd(const GNArgs& a, hipStream_t s) {
+  const long HW = (long)a.x.H * a.x.W;
+  hipLaunchKernelGGL((chan_partial_kernel<T, true>), dim3(a.nchunk, a.x.B), dim3(256), 0, s, a.x, a.part, a.nchunk, 1);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(a.x.B), dim3(256), 0, s, a.part, a.nchunk, a.x.C, a.G, HW, a.eps, a.gamma, a.beta,
+                     a.scale, a.shift, a.stat, a.coef);
+  const long total = (long)a.y.B * a.y.H * a.y.W * (a.x.C / ET<T>::VEC);
+  if (a.resample == RS_NONE) hipLaunchKernelGGL((gn_apply_kernel<T, RS_NONE>), dim3(ew_grid(total)), dim3(256), 0, s, a);
+  else if (a.resample == RS_DOWN) hipLaunchKernelGGL((gn_apply_kernel<T, RS_DOWN>), dim3(ew_grid(total)), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((gn_apply_kernel<T, RS_UP>), dim3(ew_grid(total)), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ GroupNorm + SiLU backward
+// pass 1: dv = dL/d(pre-activation) written to scratch; per (b, chunk, c): S1 = sum dv, S2 = sum dv * xhat
+template <typename T, int RS>
+__global__ __launch_bounds__(256) void gn_bwd_pass1_kernel(GNBwdArgs a) {
+  constexpr int VEC = ET<T>::VEC;
+  __shared__ float buf[256 * VEC * 2];
+  const GNArgs& f = a.f;
+  const int C = f.x.C, CV = C / VEC, PL = 256 / CV;
+  const int tid = threadIdx.x, cv = tid % CV, pl = tid / CV;
+  const int chunk = blockIdx.x, b = blockIdx.y;
+  const int H = f.x.H, W = f.x.W;
+  const long HW = (long)H * W;
+  const long per = (HW + f.nchunk - 1) / f.nchunk;
+  const long p0 = (long)chunk * per, p1 = min(HW, p0 + per);
+  const T* xp = reinterpret_cast<const T*>(f.x.p);
+  const T* dyp = reinterpret_cast<const T*>(a.dy.p);
+  T* dvp = reinterpret_cast<T*>(a.dv.p);
+  const int cpg = C / f.G;
+  float A[VEC], Bc[VEC], mean[VEC], rstd[VEC], s1[VEC], s2[VEC];
+  const float keep = 1.f - f.drop_p, inv_keep = f.drop_p > 0.f ? 1.f / keep : 1.f;
+  if (pl < PL) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const int c = cv * VEC + e;
+      A[e] = f.coef[((long)b * C + c) * 2]; Bc[e] = f.coef[((long)b * C + c) * 2 + 1];
+      const int g = c / cpg;
+      mean[e] = f.stat[((long)b * f.G + g) * 2]; rstd[e] = f.stat[((long)b * f.G + g) * 2 + 1];
+      s1[e] = 0.f; s2[e] = 0.f;
+    }
+    for (long p = p0 + pl; p < p1; p += PL) {
+      const int y = (int)(p / W), x = (int)(p % W);
+      float dh[VEC];
+      if (RS == RS_NONE) {
+        unpack<T>(ldv<T>(dyp + ((long)b * HW + p) * a.dy.ld + cv * VEC), dh);
+      } else if (RS == RS_DOWN) {
+        unpack<T>(ldv<T>(dyp + (((long)b * (H / 2) + (y >> 1)) * (W / 2) + (x >> 1)) * a.dy.ld + cv * VEC), dh);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) dh[e] *= 0.25f;
+      } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) dh[e] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float t[VEC];
+          unpack<T>(ldv<T>(dyp + (((long)b * (2 * H) + (2 * y + (q >> 1))) * (2 * W) + (2 * x + (q & 1))) * a.dy.ld + cv * VEC), t);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) dh[e] += t[e];
+        }
+      }
+      float xv[VEC]; unpack<T>(ldv<T>(xp + ((long)b * HW + p) * f.x.ld + cv * VEC), xv);
+      float dv[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        float d = dh[e];
+        if (RS == RS_NONE && f.drop_p > 0.f) {
+          const uint64_t idx = ((uint64_t)b * HW + p) * (uint64_t)C + (uint64_t)(cv * VEC + e);
+          d = hash_uniform(f.drop_seed, f.drop_stream, idx) < keep ? d * inv_keep : 0.f;
+        }
+        dv[e] = d * dsilu_f(A[e] * xv[e] + Bc[e]);
+        s1[e] += dv[e];
+        s2[e] += dv[e] * (xv[e] - mean[e]) * rstd[e];
+      }
+      stv<T>(dvp + ((long)b * HW + p) * a.dv.ld + cv * VEC, pack<T>(dv));
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { buf[(pl * C + cv * VEC + e) * 2] = s1[e]; buf[(pl * C + cv * VEC + e) * 2 + 1] = s2[e]; }
+  }
+  __syncthreads();
+  const int nout = C * 2;
+  for (int o = tid; o < nout; o += 256) {
+    float acc = 0.f;
+    for (int q = 0; q < PL; ++q) acc += buf[q * nout + o];
+    a.part2[((long)b * f.nchunk + chunk) * nout + o] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(GNBwdArgs a) {
+  __shared__ float cs[1024 * 2];
+  __shared__ float gm[64];
+  const GNArgs& f = a.f;
+  const int b = blockIdx.x, tid = threadIdx.x, C = f.x.C, G = f.G, cpg = C / G;
+  const long HW = (long)f.x.H * f.x.W;
+  for (int c = tid; c < C; c += 256) {
+    float u = 0.f, w = 0.f;
+    for (int k = 0; k < f.nchunk; ++k) { const float* pp = a.part2 + (((long)b * f.nchunk + k) * C + c) * 2; u += pp[0]; w += pp[1]; }
+    cs[c * 2] = u; cs[c * 2 + 1] = w;
+  }
+  __syncthreads();
+  if (tid < G) {
+    float m1 = 0.f, m2 = 0.f;
+    for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) {
+      const float gp = f.gamma[c] * (1.f + (f.scale ? f.scale[c] : 0.f));
+      m1 += gp * cs[c * 2]; m2 += gp * cs[c * 2 + 1];
+    }
+    const float n = (float)cpg * (float)HW;
+    gm[tid * 2] = m1 / n; gm[tid * 2 + 1] = m2 / n;
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    const int g = c / cpg;
+    const float mean = f.stat[((long)b * G + g) * 2], rstd = f.stat[((long)b * G + g) * 2 + 1];
+    const float gp = f.gamma[c] * (1.f + (f.scale ? f.scale[c] : 0.f));
+    const float m1 = gm[g * 2], m2 = gm[g * 2 + 1];
+    float* o = a.coef2 + ((long)b * C + c) * 3;
+    o[0] = rstd * gp;
+    o[1] = -rstd * rstd * m2;
+    o[2] = -rstd * m1 + rstd * rstd * m2 * mean;
+    // keep per-(b,c) sums for the parameter-gradient kernel in chunk slot 0
+    float* keepp = a.part2 + (((long)b * f.nchunk) * C + c) * 2;
+    keepp[0] = cs[c * 2]; keepp[1] = cs[c * 2 + 1];
+  }
+}
+
+__global__ void gn_param_grad_kernel(GNBwdArgs a) {
+  const GNArgs& f = a.f;
+  const int C = f.x.C;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float S1 = 0.f, S2 = 0.f;
+  for (int b = 0; b < f.x.B; ++b) { const float* pp = a.part2 + (((long)b * f.nchunk) * C + c) * 2; S1 += pp[0]; S2 += pp[1]; }
+  const float s = f.scale ? f.scale[c] : 0.f;
+  a.dgamma[c] += (1.f + s) * S2;
+  a.dbeta[c] += (1.f + s) * S1;
+  if (a.dscale) a.dscale[c] += f.gamma[c] * S2 + f.beta[c] * S1;
+  if (a.dshift) a.dshift[c] += S1;
+}
+
+template <typename T>
+__global__ void gn_bwd_pass2_kernel(GNBwdArgs a) {
+  constexpr int VEC = ET<T>::VEC;
+  const GNArgs& f = a.f;
+  const int C = f.x.C, CV = C / VEC;
+  const long HW = (long)f.x.H * f.x.W;
+  const long total = (long)f.x.B * HW * CV;
+  const T* xp = reinterpret_cast<const T*>(f.x.p);
+  const T* dvp = reinterpret_cast<const T*>(a.dv.p);
+  T* dxp = reinterpret_cast<T*>(a.dx.p);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % CV);
+    const long bp = i / CV;
+    const int b = (int)(bp / HW);
+    const float* cf = a.coef2 + ((long)b * C + cv * VEC) * 3;
+    float xv[VEC], dv[VEC], o[VEC];
+    unpack<T>(ldv<T>(xp + bp * f.x.ld + cv * VEC), xv);
+    unpack<T>(ldv<T>(dvp + bp * a.dv.ld + cv * VEC), dv);
+    if (a.accumulate) unpack<T>(ldv<T>(dxp + bp * a.dx.ld + cv * VEC), o);
+    else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) o[e] = 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) o[e] += cf[3 * e] * dv[e] + cf[3 * e + 1] * xv[e] + cf[3 * e + 2];
+    stv<T>(dxp + bp * a.dx.ld + cv * VEC, pack<T>(o));
+  }
+}
+
+template <typename T>
+hipError_t launch_gn_bwd(const GNBwdArgs& a, hipStream_t s) {
+  const GNArgs& f = a.f;
+  dim3 g1(f.nchunk, f.x.B);
+  if (f.resample == RS_NONE) hipLaunchKernelGGL((gn_bwd_pass1_kernel<T, RS_NONE>), g1, dim3(256), 0, s, a);
+  else if (f.resample == RS_DOWN) hipLaunchKernelGGL((gn_bwd_pass1_kernel<T, RS_DOWN>), g1, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((gn_bwd_pass1_kernel<T, RS_UP>), g1, dim3(256), 0, s, a);
+  hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(f.x.B), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(gn_param_grad_kernel, dim3(cdiv(f.x.C, 256)), dim3(256), 0, s, a);
+  const long total = (long)f.x.B * f.x.H * f.x.W * (f.x.C / ET<T>::VEC);
+  hipLaunchKernelGGL(gn_bwd_pass2_kernel<T>, dim3(ew_grid(total)), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ resample / add / maxpool / relu
+template <typename T, int RS, bool BWD>
+__global__ void resample_kernel(TV src, TV dst, int accumulate) {
+  // forward: dst = RS(src). backward (BWD): src is the gradient of the resampled tensor, dst the gradient of its input.
+  constexpr int VEC = ET<T>::VEC;
+  const int CV = dst.C / VEC;
+  const long total = (long)dst.B * dst.H * dst.W * CV;
+  const T* sp = reinterpret_cast<const T*>(src.p);
+  T* dp = reinterpret_cast<T*>(dst.p);
+  constexpr bool GATHER4 = (RS == RS_DOWN && !BWD) || (RS == RS_UP && BWD);   // dst pixel <- 4 src pixels
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % CV);
+    long p = i / CV;
+    const int x = (int)(p % dst.W); p /= dst.W;
+    const int y = (int)(p % dst.H);
+    const int b = (int)(p / dst.H);
+    float o[VEC];
+    if (GATHER4) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) o[e] = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float v[VEC];
+        unpack<T>(ldv<T>(sp + (((long)b * src.H + 2 * y + (q >> 1)) * src.W + 2 * x + (q & 1)) * src.ld + cv * VEC), v);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) o[e] += v[e];
+      }
+      if (RS == RS_DOWN) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) o[e] *= 0.25f;
+      }
+    } else {
+      unpack<T>(ldv<T>(sp + (((long)b * src.H + (y >> 1)) * src.W + (x >> 1)) * src.ld + cv * VEC), o);
+      if (RS == RS_DOWN) {      // backward of avg-pool
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) o[e] *= 0.25f;
+      }
+    }
+    T* q = dp + (((long)b * dst.H + y) * dst.W + x) * dst.ld + cv * VEC;
+    if (accumulate) {
+      float old[VEC]; unpack<T>(ldv<T>(q), old);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) o[e] += old[e];
+    }
+    stv<T>(q, pack<T>(o));
+  }
+}
+template <typename T>
+hipError_t launch_resample(TV x, TV y, int mode, hipStream_t s) {
+  const long total = (long)y.B * y.H * y.W * (y.C / ET<T>::VEC);
+  if (mode == RS_DOWN) hipLaunchKernelGGL((resample_kernel<T, RS_DOWN, false>), dim3(ew_grid(total)), dim3(256), 0, s, x, y, 0);
+  else hipLaunchKernelGGL((resample_kernel<T, RS_UP, false>), dim3(ew_grid(total)), dim3(256), 0, s, x, y, 0);
+  return hipGetLastError();
+}
+template <typename T>
+hipError_t launch_resample_bwd(TV dy, TV dx, int mode, int accumulate, hipStream_t s) {
+  const long total = (long)dx.B * dx.H * dx.W * (dx.C / ET<T>::VEC);
+  if (mode == RS_DOWN) hipLaunchKernelGGL((resample_kernel<T, RS_DOWN, true>), dim3(ew_grid(total)), dim3(256), 0, s, dy, dx, accumulate);
+  else hipLaunchKernelGGL((resample_kernel<T, RS_UP, true>), dim3(ew_grid(total)), dim3(256), 0, s, dy, dx, accumulate);
+  return hipGetLastError();
+}
+
+template <typename T>
+__global__ void add_kernel(TV src, TV dst, int accumulate) {
+  constexpr int VEC = ET<T>::VEC;
+  const int CV = dst.C / VEC;
+  const long total = (long)dst.B * dst.H * dst.W * CV;
+  const T* sp = reinterpret_cast<const T*>(src.p);
+  T* dp = reinterpret_cast<T*>(dst.p);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % CV); const long p = i / CV;
+    float o[VEC]; unpack<T>(ldv<T>(sp + p * src.ld + cv * VEC), o);
+    if (accumulate) {
+      float old[VEC]; unpack<T>(ldv<T>(dp + p * dst.ld + cv * VEC), old);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) o[e] += old[e];
+    }
+    stv<T>(dp + p * dst.ld + cv * VEC, pack<T>(o));
+  }
+}
+template <typename T>
+hipError_t launch_add(TV src, TV dst, int accumulate, hipStream_t s) {
+  const long total = (long)dst.B * dst.H * dst.W * (dst.C / ET<T>::VEC);
+  hipLaunchKernelGGL(add_kernel<T>, dim3(ew_grid(total)), dim3(256), 0, s, src, dst, accumulate);
+  return hipGetLastError();
+}
+
+template <typename T, bool BWD>
+__global__ void maxpool_kernel(TV x, TV y, TV dy, TV dx) {
+  // forward: y = maxpool2(x).  backward: dx = route(dy) to the first maximum of each window (aten tie rule)
+  constexpr int VEC = ET<T>::VEC;
+  const int CV = y.C / VEC;
+  const long total = (long)y.B * y.H * y.W * CV;
+  const T* xp = reinterpret_cast<const T*>(x.p);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % CV);
+    long p = i / CV;
+    const int ox = (int)(p % y.W); p /= y.W;
+    const int oy = (int)(p % y.H);
+    const int b = (int)(p / y.H);
+    float v[4][VEC];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      unpack<T>(ldv<T>(xp + (((long)b * x.H + 2 * oy + (q >> 1)) * x.W + 2 * ox + (q & 1)) * x.ld + cv * VEC), v[q]);
+    if (!BWD) {
+      float o[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) o[e] = fmaxf(fmaxf(v[0][e], v[1][e]), fmaxf(v[2][e], v[3][e]));
+      stv<T>(reinterpret_cast<T*>(y.p) + (((long)b * y.H + oy) * y.W + ox) * y.ld + cv * VEC, pack<T>(o));
+    } else {
+      float g[VEC]; unpack<T>(ldv<T>(reinterpret_cast<const T*>(dy.p) + (((long)b * y.H + oy) * y.W + ox) * dy.ld + cv * VEC), g);
+      float o[4][VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        int arg = 0; float m = v[0][e];
+#pragma unroll
+        for (int q = 1; q < 4; ++q) if (v[q][e] > m) { m = v[q][e]; arg = q; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q][e] = (q == arg) ? g[e] : 0.f;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        stv<T>(reinterpret_cast<T*>(dx.p) + (((long)b * x.H + 2 * oy + (q >> 1)) * x.W + 2 * ox + (q & 1)) * dx.ld + cv * VEC, pack<T>(o[q]));
+    }
+  }
+}
+template <typename T>
+hipError_t launch_maxpool(TV x, TV y, hipStream_t s) {
+  const long total = (long)y.B * y.H * y.W * (y.C / ET<T>::VEC);
+  hipLaunchKernelGGL((maxpool_kernel<T, false>), dim3(ew_grid(total)), dim3(256), 0, s, x, y, y, x);
+  return hipGetLastError();
+}
+template <typename T>
+hipError_t launch_maxpool_bwd(TV x, TV dy, TV dx, hipStream_t s) {
+  TV y = dy;
+  const long total = (long)y.B * y.H * y.W * (y.C / ET<T>::VEC);
+  hipLaunchKernelGGL((maxpool_kernel<T, true>), dim3(ew_grid(total)), dim3(256), 0, s, x, y, dy, dx);
+  return hipGetLastError();
+}
+
+template <typename T>
+__global__ void relu_bwd_kernel(TV y, TV dy) {
+  constexpr int VEC = ET<T>::VEC;
+  const int CV = y.C / VEC;
+  const long total = (long)y.B * y.H * y.W * CV;
+  const T* yp = reinterpret_cast<const T*>(y.p);
+  T* dp = reinterpret_cast<T*>(dy.p);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int cv = (int)(i % CV); const long p = i / CV;
+    float a[VEC], g[VEC];
+    unpack<T>(ldv<T>(yp + p * y.ld + cv * VEC), a);
+    unpack<T>(ldv<T>(dp + p * dy.ld + cv * VEC), g);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) g[e] = a[e] > 0.f ? g[e] : 0.f;
+    stv<T>(dp + p * dy.ld + cv * VEC, pack<T>(g));
+  }
+}
+template <typename T>
+hipError_t launch_relu_bwd(TV y, TV dy, hipStream_t s) {
+  const long total = (long)y.B * y.H * y.W * (y.C / ET<T>::VEC);
+  hipLaunchKernelGGL(relu_bwd_kernel<T>, dim3(ew_grid(total)), dim3(256), 0, s, y, dy);
+  return hipGetLastError();
+}
+
+__global__ void bias_grad_finalize_kernel(const float* __restrict__ part, int nchunk, int C, float* d0, float* d1) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int k = 0; k < nchunk; ++k) s += part[(long)k * C + c];
+  d0[c] += s;
+  if (d1) d1[c] += s;
+}
+template <typename T>
+hipError_t launch_bias_grad(TV dy, float* d0, float* d1, float* part, int nchunk, hipStream_t s) {
+  hipLaunchKernelGGL((chan_partial_kernel<T, false>), dim3(nchunk, 1), dim3(256), 0, s, dy, part, nchunk, 0);
+  hipLaunchKernelGGL(bias_grad_finalize_kernel, dim3(cdiv(dy.C, 256)), dim3(256), 0, s, part, nchunk, dy.C, d0, d1);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ Gaussian-encoder heads
+template <typename T>
+__global__ __launch_bounds__(256) void heads_fwd_kernel(TV x, const float* __restrict__ wmu, const float* __restrict__ bmu,
+                                                        const float* __restrict__ wls, const float* __restrict__ bls, int L,
+                                                        float* __restrict__ hbuf, float* __restrict__ mu, float* __restrict__ ls) {
+  constexpr int VEC = ET<T>::VEC;
+  __shared__ float buf[256 * VEC];
+  __shared__ float hs[1024];
+  const int C = x.C, CV = C / VEC, PL = 256 / CV;
+  const int tid = threadIdx.x, cv = tid % CV, pl = tid / CV, b = blockIdx.x;
+  const long HW = (long)x.H * x.W;
+  const T* xp = reinterpret_cast<const T*>(x.p) + (long)b * HW * x.ld;
+  float s1[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) s1[e] = 0.f;
+  if (pl < PL) {
+    for (long p = pl; p < HW; p += PL) {
+      float v[VEC]; unpack<T>(ldv<T>(xp + p * x.ld + cv * VEC), v);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) s1[e] += v[e];
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) buf[pl * C + cv * VEC + e] = s1[e];
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    float acc = 0.f;
+    for (int q = 0; q < PL; ++q) acc += buf[q * C + c];
+    acc /= (float)HW;
+    hs[c] = acc; hbuf[(long)b * C + c] = acc;
+  }
+  __syncthreads();
+  if (tid < 2 * L) {
+    const int l = tid % L; const bool is_ls = tid >= L;
+    const float* w = (is_ls ? wls : wmu) + (long)l * C;
+    float acc = is_ls ? bls[l] : bmu[l];
+    for (int c = 0; c < C; ++c) acc += w[c] * hs[c];
+    (is_ls ? ls : mu)[(long)b * L + l] = acc;
+  }
+}
+template <typename T>
+hipError_t launch_heads_fwd(TV x, const float* wmu, const float* bmu, const float* wls, const float* bls, int L, float* hbuf,
+                            float* mu, float* ls, hipStream_t s) {
+  hipLaunchKernelGGL(heads_fwd_kernel<T>, dim3(x.B), dim3(256), 0, s, x, wmu, bmu, wls, bls, L, hbuf, mu, ls);
+  return hipGetLastError();
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void heads_bwd_dx_kernel(TV dx, const float* __restrict__ wmu, const float* __restrict__ wls,
+                                                           const float* __restrict__ dmu, const float* __restrict__ dls, int L, int nchunk) {
+  constexpr int VEC = ET<T>::VEC;
+  __shared__ float dh[1024];
+  const int C = dx.C, CV = C / VEC, b = blockIdx.y, tid = threadIdx.x;
+  const long HW = (long)dx.H * dx.W;
+  for (int c = tid; c < C; c += 256) {
+    float acc = 0.f;
+    for (int l = 0; l < L; ++l) acc += dmu[(long)b * L + l] * wmu[(long)l * C + c] + dls[(long)b * L + l] * wls[(long)l * C + c];
+    dh[c] = acc / (float)HW;
+  }
+  __syncthreads();
+  const long per = (HW + nchunk - 1) / nchunk;
+  const long p0 = (long)blockIdx.x * per, p1 = min(HW, p0 + per);
+  T* dp = reinterpret_cast<T*>(dx.p) + (long)b * HW * dx.ld;
+  for (long i = p0 * CV + tid; i < p1 * CV; i += 256) {
+    const int cv = (int)(i % CV); const long p = i / CV;
+    stv<T>(dp + p * dx.ld + cv * VEC, pack<T>(&dh[cv * VEC]));
+  }
+}
+__global__ void heads_bwd_param_kernel(const float* __restrict__ hbuf, const float* __restrict__ dmu, const float* __restrict__ dls,
+                                       int B, int L, int C, float* dwmu, float* dbmu, float* dwls, float* dbls) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= L * C) return;
+  const int l = i / C, c = i % C;
+  float a = 0.f, q = 0.f, sa = 0.f, sq = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float h = hbuf[(long)b * C + c];
+    a += dmu[(long)b * L + l] * h; q += dls[(long)b * L + l] * h;
+    sa += dmu[(long)b * L + l]; sq += dls[(long)b * L + l];
+  }
+  dwmu[i] += a; dwls[i] += q;
+  if (c == 0) { dbmu[l] += sa; dbls[l] += sq; }
+}
+template <typename T>
+hipError_t launch_heads_bwd(TV xs, TV dx, const float* hbuf, const float* wmu, const float* wls, const float* dmu, const float* dls,
+                            int L, float* dwmu, float* dbmu, float* dwls, float* dbls, hipStream_t s) {
+  const long HW = (long)dx.H * dx.W;
+  const int nchunk = (int)min((long)64, (HW * (dx.C / ET<T>::VEC) + 255) / 256);
+  hipLaunchKernelGGL(heads_bwd_dx_kernel<T>, dim3(nchunk, dx.B), dim3(256), 0, s, dx, wmu, wls, dmu, dls, L, nchunk);
+  hipLaunchKernelGGL(heads_bwd_param_kernel, dim3(cdiv((long)L * dx.C, 256)), dim3(256), 0, s, hbuf, dmu, dls, dx.B, L, dx.C, dwmu, dbmu, dwls, dbls);
+  (void)xs;
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ latent sampling + KL  (prob_unet.py:84,215,255)
+__global__ void latent_fwd_kernel(LatentArgs a) {
+  __shared__ float red[256], red2[256];
+  const int tid = threadIdx.x;
+  const int BL = a.B * a.L;
+  for (int i = tid; i < BL; i += blockDim.x) {
+    const float sq = expf(a.ls_q[i]) + 1e-7f;
+    if (a.eps && a.z)
+      for (int m = 0; m < a.M; ++m) a.z[(long)m * BL + i] = a.mu_q[i] + sq * a.eps[(long)m * BL + i];
+  }
+  float tot = 0.f, tot2 = 0.f;
+  for (int b = tid; b < a.B; b += blockDim.x) {
+    float k = 0.f, k2 = 0.f;
+    for (int l = 0; l < a.L; ++l) {
+      const int i = b * a.L + l;
+      const float sq = expf(a.ls_q[i]) + 1e-7f;
+      const float mq = a.mu_q[i];
+      if (a.mu_p) {
+        const float sp = expf(a.ls_p[i]) + 1e-7f;
+        const float vr = (sq / sp) * (sq / sp), t1 = ((mq - a.mu_p[i]) / sp) * ((mq - a.mu_p[i]) / sp);
+        k += 0.5f * (vr + t1 - 1.f - logf(vr));
+      }
+      const float vr2 = sq * sq;
+      k2 += 0.5f * (vr2 + mq * mq - 1.f - logf(vr2));
+    }
+    if (a.kl) a.kl[b] = k;
+    if (a.kl2) a.kl2[b] = k2;
+    tot += k; tot2 += k2;
+  }
+  red[tid] = tot; red2[tid] = tot2;
+  __syncthreads();
+  for (int s = blockDim.x / 2; s > 0; s >>= 1) { if (tid < s) { red[tid] += red[tid + s]; red2[tid] += red2[tid + s]; } __syncthreads(); }
+  if (tid == 0 && a.scalars) { a.scalars[PU_S_KL_MEAN] = red[0] / a.B; a.scalars[PU_S_KL2_MEAN] = red2[0] / a.B; }
+}
+hipError_t launch_latent_fwd(const LatentArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(latent_fwd_kernel, dim3(1), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+__global__ void latent_bwd_kernel(LatentBwdArgs a) {
+  const LatentArgs& f = a.f;
+  const int BL = f.B * f.L;
+  const float invB = 1.f / (float)f.B;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < BL; i += gridDim.x * blockDim.x) {
+    const float eq = expf(f.ls_q[i]), sq = eq + 1e-7f, mq = f.mu_q[i];
+    const float ep = expf(f.ls_p[i]), sp = ep + 1e-7f, mp = f.mu_p[i];
+    float dmq = 0.f, dsq = 0.f;
+    if (a.dz)
+      for (int m = 0; m < f.M; ++m) { const float g = a.dz[(long)m * BL + i]; dmq += g; dsq += g * f.eps[(long)m * BL + i]; }
+    const float d = mq - mp, isp2 = 1.f / (sp * sp);
+    const float k1 = a.beta1 * invB, k2 = a.beta2 * invB;
+    dmq += k1 * d * isp2 + k2 * mq;
+    dsq += k1 * (-1.f / sq + sq * isp2) + k2 * (-1.f / sq + sq);
+    const float dmp = -k1 * d * isp2;
+    const float dsp = k1 * (1.f / sp - (sq * sq + d * d) * isp2 / sp);
+    a.dmu_q[i] = dmq; a.dls_q[i] = dsq * eq;
+    a.dmu_p[i] = dmp; a.dls_p[i] = dsp * ep;
+  }
+}
+hipError_t launch_latent_bwd(const LatentBwdArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(latent_bwd_kernel, dim3(cdiv((long)a.f.B * a.f.L, 256)), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ reconstruction loss (afCRPS pair form / L1)
+// afCRPS (prob_unet_utils.py:171-234):  per element  [(M-1) sum_j |xj-y| - (1-e) sum_{j<k} |xj-xk|] / (M (M-1) C HW), mean over B
+// d/dxj = [(M-1) sgn(xj-y) - (1-e) sum_{k!=j} sgn(xj-xk)] / (B M (M-1) C HW)
+constexpr int MAXM = 16;
+template <int KIND>
+__global__ __launch_bounds__(256) void recon_kernel(const float* __restrict__ preds, const float* __restrict__ target, float* __restrict__ dpred,
+                                                    float* scalars, int B, int M, int C, long HW, float alpha, float gscale) {
+  __shared__ float red[256];
+  const long total = (long)B * C * HW;
+  const float e = (1.f - alpha) / (float)M;
+  const float norm = KIND == PU_RECON_AFCRPS ? 1.f / ((float)B * M * (M - 1) * C * (float)HW) : 1.f / ((float)B * C * (float)HW);
+  float acc = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long p = i % HW; const int c = (int)((i / HW) % C); const int b = (int)(i / (HW * C));
+    const float y = target[i];
+    if (KIND == PU_RECON_AFCRPS) {
+      float x[MAXM];
+#pragma unroll
+      for (int m = 0; m < MAXM; ++m) if (m < M) x[m] = preds[(((long)b * M + m) * C + c) * HW + p];
+      float s_abs = 0.f, s_pair = 0.f;
+#pragma unroll
+      for (int j = 0; j < MAXM; ++j) {
+        if (j < M) {
+          s_abs += fabsf(x[j] - y);
+          float sg = 0.f;
+#pragma unroll
+          for (int k = 0; k < MAXM; ++k) {
+            if (k < M && k != j) {
+              const float d = x[j] - x[k];
+              if (k > j) s_pair += fabsf(d);
+              sg += (d > 0.f) ? 1.f : (d < 0.f ? -1.f : 0.f);
+            }
+          }
+          if (dpred) {
+            const float dy = x[j] - y;
+            const float sy = (dy > 0.f) ? 1.f : (dy < 0.f ? -1.f : 0.f);
+            dpred[(((long)b * M + j) * C + c) * HW + p] = gscale * norm * ((float)(M - 1) * sy - (1.f - e) * sg);
+          }
+        }
+      }
+      acc += ((float)(M - 1) * s_abs - (1.f - e) * s_pair) * norm;
+    } else {
+      const float x0 = preds[(((long)b * M) * C + c) * HW + p];
+      const float d = x0 - y;
+      acc += fabsf(d) * norm;
+      if (dpred) {
+        dpred[(((long)b * M) * C + c) * HW + p] = gscale * norm * ((d > 0.f) ? 1.f : (d < 0.f ? -1.f : 0.f));
+        for (int m = 1; m < M; ++m) dpred[(((long)b * M + m) * C + c) * HW + p] = 0.f;
+      }
+    }
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) { if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s]; __syncthreads(); }
+  if (threadIdx.x == 0) atomicAdd(scalars + PU_S_RECON, red[0]);
+}
+hipError_t launch_recon(int kind, const float* preds, const float* target, float* dpred, float* scalars, int B, int M, int C, long HW,
+                        float alpha, float gscale, hipStream_t s) {
+  const long total = (long)B * C * HW;
+  const unsigned g = (unsigned)min((long)2048, (total + 255) / 256);
+  if (kind == PU_RECON_AFCRPS) hipLaunchKernelGGL(recon_kernel<PU_RECON_AFCRPS>, dim3(g), dim3(256), 0, s, preds, target, dpred, scalars, B, M, C, HW, alpha, gscale);
+  else hipLaunchKernelGGL(recon_kernel<PU_RECON_L1>, dim3(g), dim3(256), 0, s, preds, target, dpred, scalars, B, M, C, HW, alpha, gscale);
+  return hipGetLastError();
+}
+__global__ void finish_scalars_kernel(float* sc, float beta0, float beta1, float beta2, int with_kl2) {
+  if (threadIdx.x == 0) sc[PU_S_TOTAL] = beta0 * sc[PU_S_RECON] + beta1 * sc[PU_S_KL_MEAN] + (with_kl2 ? beta2 * sc[PU_S_KL2_MEAN] : 0.f);
+}
+hipError_t launch_finish_scalars(float* sc, float b0, float b1, float b2, int with_kl2, hipStream_t s) {
+  hipLaunchKernelGGL(finish_scalars_kernel, dim3(1), dim3(64), 0, s, sc, b0, b1, b2, with_kl2);
+  return hipGetLastError();
+}
+
+__global__ void fill_kernel(float* p, float v, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
+}
+hipError_t launch_fill(float* p, float v, long n, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(fill_kernel, dim3(ew_grid(n)), dim3(256), 0, s, p, v, n);
+  return hipGetLastError();
+}
+
+// ------------------------------------------------------------------ explicit instantiations
+#define PU_INST(T)                                                                                                   \
+  template hipError_t launch_nchw_to_nhwc<T>(const float*, long, int, const float*, int, TV, hipStream_t);           \
+  template hipError_t launch_nhwc_to_nchw<T>(TV, int, float*, int, hipStream_t);                                     \
+  template hipError_t launch_gn_fwd<T>(const GNArgs&, hipStream_t);                                                  \
+  template hipError_t launch_gn_bwd<T>(const GNBwdArgs&, hipStream_t);                                               \
+  template hipError_t launch_resample<T>(TV, TV, int, hipStream_t);                                                  \
+  template hipError_t launch_resample_bwd<T>(TV, TV, int, int, hipStream_t);                                         \
+  template hipError_t launch_add<T>(TV, TV, int, hipStream_t);                                                       \
+  template hipError_t launch_maxpool<T>(TV, TV, hipStream_t);                                                        \
+  template hipError_t launch_maxpool_bwd<T>(TV, TV, TV, hipStream_t);                                                \
+  template hipError_t launch_relu_bwd<T>(TV, TV, hipStream_t);                                                       \
+  template hipError_t launch_bias_grad<T>(TV, float*, float*, float*, int, hipStream_t);                             \
+  template hipError_t launch_heads_fwd<T>(TV, const float*, const float*, const float*, const float*, int, float*,   \
+                                          float*, float*, hipStream_t);                                              \
+  template hipError_t launch_heads_bwd<T>(TV, TV, const float*, const float*, const float*, const float*,            \
+                                          const float*, int, float*, float*, float*, float*, hipStream_t);
+PU_INST(float)
+PU_INST(f16)
+PU_INST(bf16)
+
+}  // namespace pu

@@ -1,0 +1,104 @@
+// Internal shared definitions for libprobunet (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+namespace pu {
+
+// ------------------------------------------------------------------ element types
+typedef _Float16 f16;
+struct bf16 { uint16_t v; };   // storage-only; converted explicitly
+
+typedef float  f32x4  __attribute__((ext_vector_type(4)));
+typedef float  f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short  s16x4 __attribute__((ext_vector_type(4)));
+typedef short  s16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float bf16_to_f(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ uint16_t f_to_bf16(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // keep NaN a NaN
+  return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+template <typename T> struct ET;                       // element traits
+template <> struct ET<float> {
+  static constexpr int VEC = 4;                        // elements per 16-byte vector
+  static constexpr int DT = 0;
+  __device__ static __forceinline__ float ld(const float* p) { return *p; }
+  __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct ET<f16> {
+  static constexpr int VEC = 8;
+  static constexpr int DT = 1;
+  __device__ static __forceinline__ float ld(const f16* p) { return (float)*p; }
+  __device__ static __forceinline__ void st(f16* p, float v) { *p = (f16)v; }
+};
+template <> struct ET<bf16> {
+  static constexpr int VEC = 8;
+  static constexpr int DT = 2;
+  __device__ static __forceinline__ float ld(const bf16* p) { return bf16_to_f(p->v); }
+  __device__ static __forceinline__ void st(bf16* p, float v) { p->v = f_to_bf16(v); }
+};
+
+// 16-byte vector of T as raw bits
+struct alignas(16) V16 { uint32_t w[4]; };
+
+template <typename T> __device__ __forceinline__ void unpack(const V16& v, float* out);   // VEC floats
+template <> __device__ __forceinline__ void unpack<float>(const V16& v, float* o) {
+  o[0] = __uint_as_float(v.w[0]); o[1] = __uint_as_float(v.w[1]); o[2] = __uint_as_float(v.w[2]); o[3] = __uint_as_float(v.w[3]);
+}
+template <> __device__ __forceinline__ void unpack<f16>(const V16& v, float* o) {
+  const f16* h = reinterpret_cast<const f16*>(&v);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = (float)h[i];
+}
+template <> __device__ __forceinline__ void unpack<bf16>(const V16& v, float* o) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { o[2 * i] = __uint_as_float(v.w[i] << 16); o[2 * i + 1] = __uint_as_float(v.w[i] & 0xffff0000u); }
+}
+template <typename T> __device__ __forceinline__ V16 pack(const float* in);
+template <> __device__ __forceinline__ V16 pack<float>(const float* in) {
+  V16 v; v.w[0] = __float_as_uint(in[0]); v.w[1] = __float_as_uint(in[1]); v.w[2] = __float_as_uint(in[2]); v.w[3] = __float_as_uint(in[3]); return v;
+}
+template <> __device__ __forceinline__ V16 pack<f16>(const float* in) {
+  V16 v; f16* h = reinterpret_cast<f16*>(&v);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) h[i] = (f16)in[i];
+  return v;
+}
+template <> __device__ __forceinline__ V16 pack<bf16>(const float* in) {
+  V16 v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v.w[i] = (uint32_t)f_to_bf16(in[2 * i]) | ((uint32_t)f_to_bf16(in[2 * i + 1]) << 16);
+  return v;
+}
+__device__ __forceinline__ V16 zero16() { V16 v; v.w[0] = v.w[1] = v.w[2] = v.w[3] = 0; return v; }
+
+// ------------------------------------------------------------------ tensor view (NHWC, strided pixel rows)
+struct TV {
+  void* p = nullptr;     // element (b,y,x,c) at p[((b*H + y)*W + x)*ld + c]
+  int B = 0, H = 0, W = 0, C = 0, ld = 0;
+  __host__ __device__ size_t pixels() const { return (size_t)B * H * W; }
+};
+
+__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
+__device__ __forceinline__ float dsilu_f(float v) { float s = 1.0f / (1.0f + __expf(-v)); return s * (1.0f + v * (1.0f - s)); }
+
+// counter-hash RNG for dropout: uniform in [0,1) from (seed, stream id, element index). Regenerated in backward.
+__device__ __forceinline__ float hash_uniform(uint64_t seed, uint32_t stream, uint64_t idx) {
+  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1) + ((uint64_t)stream << 40);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+
+inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+inline int rup(int a, int b) { return (a + b - 1) / b * b; }
+
+}  // namespace pu

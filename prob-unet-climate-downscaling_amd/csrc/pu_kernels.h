@@ -1,0 +1,123 @@
+// Kernel launch interface shared by the engine and the kernel translation units.
+#pragma once
+#include "pu_common.h"
+
+namespace pu {
+
+// ---------------------------------------------------------------- convolution
+struct ConvArgs {
+  const void* in; int in_ld; int Cin;            // NHWC input view, logical channels
+  const void* wpk; int cin_pk; int cout_pk; int taps;   // packed weights [cout_pk][taps][cin_pk]
+  const float* bias;                             // fp32 [Cout] or null
+  const void* res; int res_ld;                   // residual (same shape as out) or null
+  void* out; int out_ld; int Cout;
+  int B, H, W;
+  int relu; int accumulate;
+};
+struct WgradArgs {
+  const void* dy; int dy_ld; int Cout;
+  const void* in; int in_ld; int Cin;
+  float* dw;                                     // fp32 [Cout][Cin][ks][ks], atomically accumulated
+  int B, H, W; int taps;
+};
+struct PackDesc { long src_off; long dst_off; int Cout, Cin, taps, rows_pk, k_pk, mode; };
+
+template <typename T> hipError_t launch_conv(const ConvArgs&, hipStream_t);
+template <typename T> hipError_t launch_wgrad(const WgradArgs&, hipStream_t);
+template <typename T> hipError_t launch_pack(const float* params, void* packed, const PackDesc* descs_dev, int ndesc, hipStream_t);
+
+// ---------------------------------------------------------------- layout / elementwise
+// NCHW fp32 (two optional sources concatenated along C: src0 has c0 planes, src1 has c1 planes) -> NHWC T with
+// C_alloc >= c0+c1 channels (extra channels zero). bstride0: batch stride of src0 in elements (0 = broadcast).
+template <typename T> hipError_t launch_nchw_to_nhwc(const float* src0, long bstride0, int c0, const float* src1, int c1,
+                                                     TV dst, hipStream_t);
+// NHWC T (first C channels) -> NCHW fp32 [B,C,H,W]; accumulate=1 adds into dst
+template <typename T> hipError_t launch_nhwc_to_nchw(TV src, int C, float* dst, int accumulate, hipStream_t);
+
+enum { RS_NONE = 0, RS_DOWN = 1, RS_UP = 2 };
+
+// GroupNorm(+adaptive scale/shift)+SiLU(+dropout)(+2x resample) on NHWC tensors.
+struct GNArgs {
+  TV x;                       // input [B,H,W,C]
+  TV y;                       // output (H,W halved/doubled for RS_DOWN/RS_UP)
+  int G; float eps;
+  const float* gamma; const float* beta;          // fp32 [C]
+  const float* scale; const float* shift;         // fp32 [C] each or null (adaptive: y = silu(gn*(1+scale)+shift))
+  int resample;
+  float drop_p; uint64_t drop_seed; uint32_t drop_stream;   // drop_p == 0 -> no dropout
+  // workspaces (fp32): part [B][nchunk][C][2], stat [B][G][2] (mean, rstd), coef [B][C][2] (A, Bc)
+  float* part; float* stat; float* coef; int nchunk;
+};
+template <typename T> hipError_t launch_gn_fwd(const GNArgs&, hipStream_t);
+struct GNBwdArgs {
+  GNArgs f;                   // same as forward (x, coef, stat are the saved forward values)
+  TV dy;                      // grad wrt y (resampled geometry)
+  TV dv;                      // scratch [B,H,W,C] (x geometry) for the pre-activation gradient
+  TV dx; int accumulate;      // grad wrt x
+  float* dgamma; float* dbeta; float* dscale; float* dshift;   // fp32 [C], ADDED into (nullable scale/shift)
+  float* part2;               // [B][nchunk][C][2]
+  float* coef2;               // [B][C][3] (P, Q, R)
+};
+template <typename T> hipError_t launch_gn_bwd(const GNBwdArgs&, hipStream_t);
+
+template <typename T> hipError_t launch_resample(TV x, TV y, int mode, hipStream_t);                      // y = down/up(x)
+template <typename T> hipError_t launch_resample_bwd(TV dy, TV dx, int mode, int accumulate, hipStream_t); // adjoint
+template <typename T> hipError_t launch_add(TV src, TV dst, int accumulate, hipStream_t);                  // dst (+)= src
+template <typename T> hipError_t launch_maxpool(TV x, TV y, hipStream_t);
+template <typename T> hipError_t launch_maxpool_bwd(TV x, TV dy, TV dx, hipStream_t);                      // dx written
+template <typename T> hipError_t launch_relu_bwd(TV y, TV dy, hipStream_t);                                // dy *= (y>0), in place
+// dbias[c] += sum over pixels of dy[..., c]; part: fp32 [nchunk][C]
+template <typename T> hipError_t launch_bias_grad(TV dy, float* dbias0, float* dbias1_or_null, float* part, int nchunk, hipStream_t);
+
+// ---------------------------------------------------------------- Gaussian-encoder heads / latent / losses
+// h[b,c] = mean over pixels; mu = Wmu h + bmu; ls = Wls h + bls.  hbuf fp32 [B][C]
+template <typename T> hipError_t launch_heads_fwd(TV x, const float* wmu, const float* bmu, const float* wls, const float* bls,
+                                                  int L, float* hbuf, float* mu, float* ls, hipStream_t);
+template <typename T> hipError_t launch_heads_bwd(TV x_shape, TV dx, const float* hbuf, const float* wmu, const float* wls,
+                                                  const float* dmu, const float* dls, int L,
+                                                  float* dwmu, float* dbmu, float* dwls, float* dbls, hipStream_t);
+struct LatentArgs {
+  const float* mu_q; const float* ls_q; const float* mu_p; const float* ls_p;   // [B,L]
+  const float* eps;            // [M,B,L]
+  float* z;                    // [M,B,L]
+  float* kl; float* kl2;       // [B]
+  float* scalars;              // PU_NUM_SCALARS; kernel writes KL_MEAN, KL2_MEAN (fwd)
+  int B, L, M;
+};
+hipError_t launch_latent_fwd(const LatentArgs&, hipStream_t);
+struct LatentBwdArgs {
+  LatentArgs f;
+  const float* dz;             // [M,B,L] (d total / d z), nullable
+  float beta1, beta2;
+  float* dmu_q; float* dls_q; float* dmu_p; float* dls_p;   // [B,L] written
+};
+hipError_t launch_latent_bwd(const LatentBwdArgs&, hipStream_t);
+
+// reconstruction loss on preds [B,M,C,HW] fp32 vs target [B,C,HW] fp32.
+// Adds beta0-free loss value into scalars[PU_S_RECON] (must be zeroed before) and writes dpred = gscale * dloss/dpred.
+hipError_t launch_recon(int kind, const float* preds, const float* target, float* dpred_or_null, float* scalars,
+                        int B, int M, int C, long HW, float alpha, float gscale, hipStream_t);
+hipError_t launch_finish_scalars(float* scalars, float beta0, float beta1, float beta2, int with_kl2, hipStream_t);
+
+// ---------------------------------------------------------------- Fcomb (fused three 1x1 layers)
+struct FcombArgs {
+  TV feat;                     // NHWC T [Bf,H,W,F] (Bf == B, or 1 with bcast=1)
+  int bcast;
+  const float* z;              // [M,B,L]
+  const float* w0; const float* b0; const float* w1; const float* b1; const float* w2; const float* b2;  // fp32 params (reference layout)
+  int F, L, Cout, B, M;
+  float* out;                  // fp32 [B,M,Cout,H,W]
+};
+template <typename T> hipError_t launch_fcomb_fwd(const FcombArgs&, hipStream_t);
+struct FcombBwdArgs {
+  FcombArgs f;
+  const float* dout;           // fp32 [B,M,Cout,H,W]
+  TV dfeat; int dfeat_accumulate;   // NHWC T grad wrt feat (nullable p)
+  float* dz;                   // [M,B,L] written (must be zeroed by caller) or null
+  float* dw0; float* db0; float* dw1; float* db1; float* dw2; float* db2;   // ADDED (atomics)
+};
+template <typename T> hipError_t launch_fcomb_bwd(const FcombBwdArgs&, hipStream_t);
+
+hipError_t launch_fill(float* p, float v, long n, hipStream_t);
+
+}  // namespace pu
