@@ -104,11 +104,12 @@ int pu_fcomb_bwd(pu_ctx*, const float* dout, float* dfeat, float* dz, void* stre
 
 /* ---- fused training step (replaces model.elbo(...) + loss.backward(), train_prob_unet_model.py:133-140) -- */
 /* eps: [M,B,L] reparameterisation noise (required: the caller owns the RNG, explicit for parity).
- * out_scalars: PU_NUM_SCALARS floats; out_kl: [B]. with_backward != 0 also runs the whole backward and WRITES
- * d(total)/d(param) into flat_grads (all entries, zeros for dead parameters). */
+ * out_scalars: PU_NUM_SCALARS floats; out_kl: [B] KL(q||p); out_kl2 (nullable): [B] KL(q||N(0,I)).
+ * with_backward != 0 also runs the whole backward and WRITES d(total)/d(param) into flat_grads (all entries,
+ * zeros for dead parameters). */
 int pu_elbo_fwd_bwd(pu_ctx*, const float* x, const float* target, const float* eps, int B, int M, int recon_kind,
                     float beta0, float beta1, float beta2, float alpha, int train, uint64_t drop_seed,
-                    int with_backward, float* out_scalars, float* out_kl, void* stream);
+                    int with_backward, float* out_scalars, float* out_kl, float* out_kl2, void* stream);
 
 /* ---- sampling (replaces n x model(x, training=False), train_prob_unet_model.py:244-247, and
  *      latent_exploration.py:119-129): U-Net + prior (or posterior if target given) ONCE, then n x Fcomb. ---- */
@@ -127,11 +128,12 @@ double pu_elbo_fwd_flops(pu_ctx*, int B, int M);
  * All pointers device fp32. Syncs the stream. */
 int pu_op_conv(int dtype, int mode, int ks, int relu, int B, int Cin, int Cout, int H, int W,
                const float* x, const float* w, const float* bias, const float* dy, float* out, void* stream);
-/* GroupNorm(+scale/shift)+SiLU with optional 2x resample (0 none, 1 avg-pool down, 2 nearest up), forward and
- * backward, on NCHW fp32 tensors. Syncs. */
+/* GroupNorm(+scale/shift)+SiLU(+dropout drop_p with the counter-hash mask of drop_seed; resample 0 only) with optional
+ * 2x resample (0 none, 1 avg-pool down, 2 nearest up), forward and backward, on NCHW fp32 tensors. Syncs. */
 int pu_op_gnsilu(int dtype, int resample, int B, int C, int H, int W, const float* x, const float* gamma,
                  const float* beta, const float* scale_shift_or_null, float* y,
-                 const float* dy_or_null, float* dx, float* dgamma, float* dbeta, float* dscale_shift, void* stream);
+                 const float* dy_or_null, float* dx, float* dgamma, float* dbeta, float* dscale_shift,
+                 float drop_p, uint64_t drop_seed, void* stream);
 
 #ifdef __cplusplus
 }

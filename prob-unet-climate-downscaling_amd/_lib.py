@@ -62,13 +62,13 @@ def lib():
     L.pu_fcomb_fwd.restype = i32; L.pu_fcomb_fwd.argtypes = [vp, vp, i64, vp, vp, i32, vp]
     L.pu_fcomb_bwd.restype = i32; L.pu_fcomb_bwd.argtypes = [vp, vp, vp, vp, vp]
     L.pu_elbo_fwd_bwd.restype = i32
-    L.pu_elbo_fwd_bwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, f32, f32, f32, f32, i32, u64, i32, vp, vp, vp]
+    L.pu_elbo_fwd_bwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, f32, f32, f32, f32, i32, u64, i32, vp, vp, vp, vp]
     L.pu_sample.restype = i32; L.pu_sample.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp]
     L.pu_elbo_fwd_flops.restype = C.c_double; L.pu_elbo_fwd_flops.argtypes = [vp, i32, i32]
     L.pu_op_conv.restype = i32
     L.pu_op_conv.argtypes = [i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]
     L.pu_op_gnsilu.restype = i32
-    L.pu_op_gnsilu.argtypes = [i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.pu_op_gnsilu.argtypes = [i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, u64, vp]
     _lib = L
     return L
 

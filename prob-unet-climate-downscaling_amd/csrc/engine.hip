@@ -775,7 +775,7 @@ int pu_fcomb_bwd(pu_ctx* c, const float* dout, float* dfeat, float* dz, void* st
 
 int pu_elbo_fwd_bwd(pu_ctx* c, const float* x, const float* target, const float* eps, int B, int M, int recon_kind,
                     float beta0, float beta1, float beta2, float alpha, int train, uint64_t seed, int with_backward,
-                    float* out_scalars, float* out_kl, void* stream) {
+                    float* out_scalars, float* out_kl, float* out_kl2, void* stream) {
   if (!c || !x || !target || !eps) return PU_ERR_INVALID;
   int r; if ((r = check_B(c, B))) return r;
   if (M < 1 || M > c->cfg.max_members) FAIL(PU_ERR_INVALID, "M=%d outside [1, max_members=%d]", M, c->cfg.max_members);
@@ -807,6 +807,7 @@ int pu_elbo_fwd_bwd(pu_ctx* c, const float* x, const float* target, const float*
     CKH(launch_finish_scalars(c->scal, beta0, beta1, beta2, l1 ? 1 : 0, s));
     if (out_scalars) CKH(hipMemcpyAsync(out_scalars, c->scal, PU_NUM_SCALARS * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (out_kl) CKH(hipMemcpyAsync(out_kl, c->kl, (size_t)B * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (out_kl2) CKH(hipMemcpyAsync(out_kl2, c->kl2, (size_t)B * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (!with_backward) return PU_OK;
     // ---------------- backward
     CKH(hipMemsetAsync(c->grads, 0, (size_t)c->nparams * sizeof(float), s));
@@ -923,7 +924,7 @@ extern "C" int pu_op_conv(int dtype, int mode, int ks, int relu, int B, int Cin,
 
 template <typename T>
 static int op_gn_t(int resample, int B, int C, int H, int W, const float* x, const float* gamma, const float* beta, const float* ss, float* y,
-                   const float* dy, float* dx, float* dgamma, float* dbeta, float* dss, hipStream_t s) {
+                   const float* dy, float* dx, float* dgamma, float* dbeta, float* dss, float drop_p, uint64_t drop_seed, hipStream_t s) {
   int rc = PU_OK;
   const size_t esz = sizeof(T);
   const int OH = resample == RS_DOWN ? H / 2 : (resample == RS_UP ? H * 2 : H), OW = resample == RS_DOWN ? W / 2 : (resample == RS_UP ? W * 2 : W);
@@ -938,6 +939,7 @@ static int op_gn_t(int resample, int B, int C, int H, int W, const float* x, con
   ty.p = yb; ty.B = B; ty.H = OH; ty.W = OW; ty.C = C; ty.ld = C;
   memset(&a, 0, sizeof a);
   a.x = tx; a.y = ty; a.G = G; a.eps = 1e-5f; a.gamma = gamma; a.beta = beta; a.scale = ss; a.shift = ss ? ss + C : nullptr; a.resample = resample;
+  a.drop_p = resample == RS_NONE ? drop_p : 0.f; a.drop_seed = drop_seed; a.drop_stream = 7;
   a.part = ws; a.nchunk = nchunk; a.stat = ws + (size_t)B * nchunk * C * 2; a.coef = a.stat + (size_t)B * G * 2;
   CK0(launch_nchw_to_nhwc<T>(x, (long)C * H * W, C, nullptr, 0, tx, s));
   CK0(launch_gn_fwd<T>(a, s));
@@ -961,11 +963,12 @@ done:
 }
 
 extern "C" int pu_op_gnsilu(int dtype, int resample, int B, int C, int H, int W, const float* x, const float* gamma, const float* beta,
-                 const float* ss, float* y, const float* dy, float* dx, float* dgamma, float* dbeta, float* dss, void* stream) {
+                 const float* ss, float* y, const float* dy, float* dx, float* dgamma, float* dbeta, float* dss,
+                 float drop_p, uint64_t drop_seed, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (C % 8) return PU_ERR_INVALID;
-  if (dtype == PU_F32) return op_gn_t<float>(resample, B, C, H, W, x, gamma, beta, ss, y, dy, dx, dgamma, dbeta, dss, s);
-  if (dtype == PU_F16) return op_gn_t<f16>(resample, B, C, H, W, x, gamma, beta, ss, y, dy, dx, dgamma, dbeta, dss, s);
-  if (dtype == PU_BF16) return op_gn_t<bf16>(resample, B, C, H, W, x, gamma, beta, ss, y, dy, dx, dgamma, dbeta, dss, s);
+  if (dtype == PU_F32) return op_gn_t<float>(resample, B, C, H, W, x, gamma, beta, ss, y, dy, dx, dgamma, dbeta, dss, drop_p, drop_seed, s);
+  if (dtype == PU_F16) return op_gn_t<f16>(resample, B, C, H, W, x, gamma, beta, ss, y, dy, dx, dgamma, dbeta, dss, drop_p, drop_seed, s);
+  if (dtype == PU_BF16) return op_gn_t<bf16>(resample, B, C, H, W, x, gamma, beta, ss, y, dy, dx, dgamma, dbeta, dss, drop_p, drop_seed, s);
   return PU_ERR_INVALID;
 }

@@ -705,10 +705,13 @@ __global__ void latent_bwd_kernel(LatentBwdArgs a) {
       for (int m = 0; m < f.M; ++m) { const float g = a.dz[(long)m * BL + i]; dmq += g; dsq += g * f.eps[(long)m * BL + i]; }
     const float d = mq - mp, isp2 = 1.f / (sp * sp);
     const float k1 = a.beta1 * invB, k2 = a.beta2 * invB;
+    // d/dsq = (sq^2 - sp^2) / (sq sp^2), d/dsp = (sp^2 - sq^2 - d^2) / sp^3: written with (a-b)(a+b) so that q ~ p
+    // does not cancel catastrophically in fp32
+    const float dif = (sq - sp) * (sq + sp);
     dmq += k1 * d * isp2 + k2 * mq;
-    dsq += k1 * (-1.f / sq + sq * isp2) + k2 * (-1.f / sq + sq);
+    dsq += k1 * dif * isp2 / sq + k2 * (sq - 1.f) * (sq + 1.f) / sq;
     const float dmp = -k1 * d * isp2;
-    const float dsp = k1 * (1.f / sp - (sq * sq + d * d) * isp2 / sp);
+    const float dsp = k1 * (-dif - d * d) * isp2 / sp;
     a.dmu_q[i] = dmq; a.dls_q[i] = dsq * eq;
     a.dmu_p[i] = dmp; a.dls_p[i] = dsp * ep;
   }

@@ -1,0 +1,715 @@
+"""Drop-in host side of the MI355X Probabilistic U-Net engine.
+
+Mirrors the interface of the reference class `ProbabilisticUNet` (src/prob_unet.py:140-267 of
+MaryamAlipourH/prob-unet-climate-downscaling) so that train_prob_unet_model.py / latent_exploration*.py
+call patterns run unchanged:
+
+    model = ProbabilisticUNet(input_channels, num_classes, latent_dim, num_filters, model_channels,
+                              channel_mult, beta_0, beta_1, beta_2).to("cuda")
+    loss, recon_list, kl_div = model.elbo(inputs, targets, timestamps, M=5)     # train_prob_unet_model.py:133
+    optimizer.zero_grad(); loss.backward(); optimizer.step()                    # :139-141
+    out = model(inputs, t=timestamps, training=False)                           # :245
+    feat = model.unet(x); p = model.prior(x); out = model.fcomb(feat.expand(K, -1, -1, -1), z)   # latent_exploration.py:119-129
+
+All arithmetic runs in libprobunet.so (hand-written HIP for gfx950) through the C ABI of include/probunet.h;
+this file only owns the nn.Parameters (reference state_dict keys, shapes and initialisation order), the autograd
+plumbing and the torch.distributed gradient all-reduce.  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.distributions import Independent, Normal
+
+from . import _lib as L
+
+
+# ----------------------------------------------------------------------------------------------- param tree
+class _Holder(nn.Module):
+    """A parameter container standing in for one reference sub-module (Conv2d / GroupNorm / Linear / nn.Conv2d)."""
+
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("this module only holds parameters; compute runs in libprobunet.so")
+
+
+class _IndexedHolders(nn.Module):
+    """nn.Sequential look-alike: integer-indexable children (fcomb.layers[0], prior.encoder[7] ...)."""
+
+    def __getitem__(self, i):
+        return getattr(self, str(i))
+
+    def __len__(self):
+        return len(self._modules)
+
+
+def _ensure_child(parent: nn.Module, name: str, cls):
+    if name not in parent._modules:
+        parent.add_module(name, cls())
+    return parent._modules[name]
+
+
+# ----------------------------------------------------------------------------------------------- init replay
+def _weight_init(shape, fan_in):
+    """kaiming_uniform of the reference U-Net (networks.py:21-26): sqrt(3/fan_in) * U(-1, 1)."""
+    return np.sqrt(3 / fan_in) * (torch.rand(*shape) * 2 - 1)
+
+
+def _truncated_normal_(t: torch.Tensor, std: float):
+    """prob_unet_utils.py:10-16: 4 normal draws per element, first one inside (-2, 2), times std."""
+    tmp = t.new_empty(tuple(t.shape) + (4,)).normal_()
+    valid = (tmp < 2) & (tmp > -2)
+    ind = valid.max(-1, keepdim=True)[1]
+    t.copy_(tmp.gather(-1, ind).squeeze(-1))
+    t.mul_(std)
+
+
+def _init_reference_order(model: "ProbabilisticUNet"):
+    """Fill every parameter consuming torch's global CPU generator in exactly the order the reference constructor
+    does (UNet: networks.py:243-297; prior/posterior/fcomb: nn.Conv2d default init, then init_weights,
+    prob_unet_utils.py:18-23), so that `torch.manual_seed(s); ProbabilisticUNet(...)` reproduces the reference's
+    initial state_dict (pinned by tests/golden/*.json `init_seed42`)."""
+    P = dict(model.named_parameters())
+    s13 = np.sqrt(1 / 3)
+    with torch.no_grad():
+        emb = model.model_channels * 4
+        P["unet.map_label.weight"].copy_(np.sqrt(1 / 1) * torch.randn(emb, 1) * np.sqrt(1))
+        names = [n for n in P if n.startswith("unet.")]
+        # group by module prefix in registration order
+        seen = []
+        for n in names:
+            pre = n.rsplit(".", 1)[0]
+            if pre not in seen:
+                seen.append(pre)
+        for pre in seen:
+            if pre == "unet.map_label":
+                continue
+            leaf = pre.rsplit(".", 1)[1]
+            w = P.get(pre + ".weight"); b = P.get(pre + ".bias")
+            if leaf.startswith("norm") or leaf == "out_norm":
+                w.fill_(1.0); b.fill_(0.0)
+                continue
+            zero = leaf in ("conv1", "out_conv")
+            fan_in = w[0].numel() if w.dim() == 4 else w.shape[1]
+            wv = _weight_init(list(w.shape), fan_in) * (0 if zero else s13)
+            bv = _weight_init([b.shape[0]], fan_in) * (0 if zero else s13)
+            w.copy_(wv); b.copy_(bv)
+
+        def conv_default(cout, cin, k):
+            return nn.Conv2d(cin, cout, kernel_size=k, padding=k // 2)   # consumes the generator like the reference
+
+        def init_weights_(m):
+            nn.init.kaiming_normal_(m.weight, mode="fan_in", nonlinearity="relu")
+            _truncated_normal_(m.bias.data, 0.001)
+
+        cin0 = model.input_channels
+        for net, ref_cin0 in (("prior", cin0), ("posterior", 2 * cin0)):
+            mods = []
+            keys = [n.rsplit(".", 1)[0] for n in P if n.startswith(net + ".") and n.endswith(".weight")]
+            for k in keys:
+                shp = list(P[k + ".weight"].shape)
+                if k == "posterior.encoder.0":
+                    shp[1] = ref_cin0               # reference stem has 2*Cin planes (prob_unet.py:27-28)
+                mods.append((k, conv_default(shp[0], shp[1], shp[2])))
+            for k, m in mods:
+                init_weights_(m)
+            for k, m in mods:
+                wv = m.weight.data
+                if k == "posterior.encoder.0":
+                    wv = wv[:, : P[k + ".weight"].shape[1]]
+                P[k + ".weight"].copy_(wv); P[k + ".bias"].copy_(m.bias.data)
+        mods = []
+        for k in ("fcomb.layers.0", "fcomb.layers.2", "fcomb.layers.4"):
+            shp = P[k + ".weight"].shape
+            mods.append((k, conv_default(shp[0], shp[1], 1)))
+        for k, m in mods:
+            init_weights_(m)
+        for k, m in mods:
+            P[k + ".weight"].copy_(m.weight.data); P[k + ".bias"].copy_(m.bias.data)
+
+
+# ----------------------------------------------------------------------------------------------- autograd glue
+class _DeliverGrads(torch.autograd.Function):
+    """Identity on `value`; in backward, scales the engine's parameter gradients by grad_output and delivers them
+    to the nn.Parameters of `owner` in [lo, hi) (flat offsets).  `anchor` is a dummy leaf that makes autograd call us."""
+
+    @staticmethod
+    def forward(ctx, value, anchor, owner, lo, hi):
+        ctx.owner, ctx.lo, ctx.hi = owner, lo, hi
+        return value.view_as(value)
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.owner._deliver(g, ctx.lo, ctx.hi)
+        return None, None, None, None, None
+
+
+class _UNetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, anchor, owner):
+        ctx.owner = owner
+        return owner._unet_fwd(x)
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        o = ctx.owner
+        lo, hi = o._ranges["unet"]
+        o._engine_grads[lo:hi].zero_()
+        L.check(L.lib().pu_unet_bwd(o._ctx, L.ptr(dfeat.contiguous().float()), L.current_stream()), o._ctx, "pu_unet_bwd")
+        o._deliver(None, lo, hi)
+        return None, None, None
+
+
+class _GaussFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, target, anchor, owner, which):
+        ctx.owner, ctx.which = owner, which
+        mu, ls = owner._gauss_fwd(which, x, target)
+        return mu, ls
+
+    @staticmethod
+    def backward(ctx, dmu, dls):
+        o = ctx.owner
+        lo, hi = o._ranges["posterior" if ctx.which == L.PU_POSTERIOR else "prior"]
+        o._engine_grads[lo:hi].zero_()
+        dmu = torch.zeros_like(o._last_mu[ctx.which]) if dmu is None else dmu.contiguous().float()
+        dls = torch.zeros_like(dmu) if dls is None else dls.contiguous().float()
+        L.check(L.lib().pu_gauss_bwd(o._ctx, ctx.which, L.ptr(dmu), L.ptr(dls), L.current_stream()), o._ctx, "pu_gauss_bwd")
+        o._deliver(None, lo, hi)
+        return None, None, None, None, None
+
+
+class _FcombFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, z, anchor, owner):
+        ctx.owner = owner
+        ctx.shape = tuple(feat.shape)
+        return owner._fcomb_fwd(feat, z)
+
+    @staticmethod
+    def backward(ctx, dout):
+        o = ctx.owner
+        lo, hi = o._ranges["fcomb"]
+        o._engine_grads[lo:hi].zero_()
+        B = dout.shape[0]
+        dfeat = torch.empty(ctx.shape, device=dout.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
+        dz = torch.empty(B, o.latent_dim, device=dout.device, dtype=torch.float32)
+        L.check(L.lib().pu_fcomb_bwd(o._ctx, L.ptr(dout.contiguous().float()), L.ptr(dfeat), L.ptr(dz), L.current_stream()),
+                o._ctx, "pu_fcomb_bwd")
+        o._deliver(None, lo, hi)
+        return dfeat, dz, None, None
+
+
+# ----------------------------------------------------------------------------------------------- sub-modules
+class _UNetModule(nn.Module):
+    """model.unet(x) -> [B, F0, H, W]  (networks.py:299-333)."""
+
+    def forward(self, x):
+        o = self._owner()
+        return _UNetFn.apply(x, o._anchor_t(), o)
+
+
+class _GaussianModule(nn.Module):
+    """model.prior(x) / model.posterior(x, target) -> Independent(Normal(mu, exp(log_sigma) + 1e-7), 1)
+    (prob_unet.py:56-85)."""
+
+    def forward(self, x, target=None):
+        o = self._owner()
+        which = L.PU_POSTERIOR if self._posterior else L.PU_PRIOR
+        if which == L.PU_POSTERIOR and target is None:
+            raise ValueError("posterior needs a target")
+        mu, ls = _GaussFn.apply(x, target if which == L.PU_POSTERIOR else None, o._anchor_t(), o, which)
+        return Independent(Normal(loc=mu, scale=torch.exp(ls) + 1e-7), 1)
+
+
+class _FcombModule(nn.Module):
+    """model.fcomb(feature_map, z) -> [B, Cout, H, W]  (prob_unet.py:120-138)."""
+
+    def tile(self, a, dim, n_tile):
+        """TensorFlow-style tile (prob_unet.py:109-118): element i of `dim` repeated n_tile times in place."""
+        return a.repeat_interleave(n_tile, dim=dim)
+
+    def forward(self, feature_map, z):
+        o = self._owner()
+        return _FcombFn.apply(feature_map, z, o._anchor_t(), o)
+
+
+# ----------------------------------------------------------------------------------------------- the model
+class ProbabilisticUNet(nn.Module):
+    """MI355X engine behind the reference constructor signature (prob_unet.py:146).
+
+    Extra keyword-only arguments (all optional): dtype ("f32" parity path | "f16" | "bf16" MFMA paths),
+    max_batch / max_members (engine planning; grown on demand), recon ("afcrps" | "l1"), dropout.
+    """
+
+    def __init__(self, input_channels, num_classes, latent_dim, num_filters, model_channels, channel_mult,
+                 beta_0, beta_1, beta_2, *, dtype: str = "f32", max_batch: int = 0, max_members: int = 0,
+                 recon: str = "afcrps", dropout: float = 0.10, init: bool = True):
+        super().__init__()
+        self.input_channels = int(input_channels)
+        self.num_classes = int(num_classes)
+        self.latent_dim = int(latent_dim)
+        self.num_filters = [int(v) for v in num_filters]
+        self.model_channels = int(model_channels)
+        self.channel_mult = [int(v) for v in channel_mult]
+        self.beta_0, self.beta_1, self.beta_2 = beta_0, beta_1, beta_2
+        if len(self.num_filters) != len(self.channel_mult):
+            raise ValueError("num_filters and channel_mult must have the same length")
+        if dtype not in L.DTYPES:
+            raise ValueError(f"dtype must be one of {sorted(L.DTYPES)}")
+        self.compute_dtype = dtype
+        self.recon = recon
+        self.dropout = float(dropout)
+        self.sync_scalars = True          # reference returns python floats (.item()); set False to keep device scalars
+        self.prior_latent_space = None
+        self.posterior_latent_space = None
+        self._want_batch, self._want_members = int(max_batch), int(max_members)
+        self._ctx = None
+        self._ctx_key = None
+        self._flat = None                 # engine-bound flat fp32 parameters
+        self._engine_grads = None         # engine-written flat fp32 gradients (scratch, overwritten per call)
+        self._flat_grad = None            # what p.grad aliases (stable across calls)
+        self._anchor = None
+        self._step = 0
+        self._last_mu = {}
+        self._dp_group = None
+        self._dp_world = 1
+
+        # ---- parameter tree from the engine's own table (names/shapes/order of the reference state_dict)
+        table = self._query_table()
+        self._table = table
+        self.unet = _UNetModule(); self.prior = _GaussianModule(); self.posterior = _GaussianModule(); self.fcomb = _FcombModule()
+        self.prior._posterior = False; self.posterior._posterior = True
+        import weakref
+        ref = weakref.ref(self)
+        for m in (self.unet, self.prior, self.posterior, self.fcomb):
+            object.__setattr__(m, "_owner", ref)
+        for name, shape, off, is_buf in table:
+            parts = name.split(".")
+            node = getattr(self, parts[0])
+            for i, p in enumerate(parts[1:-1]):
+                if p in ("enc", "dec"):
+                    cls = nn.ModuleDict
+                elif p in ("encoder", "layers"):
+                    cls = _IndexedHolders
+                else:
+                    cls = _Holder
+                if isinstance(node, nn.ModuleDict):
+                    if p not in node:
+                        node[p] = cls()
+                    node = node[p]
+                else:
+                    node = _ensure_child(node, p, cls)
+            if is_buf:
+                node.register_buffer(parts[-1], torch.full(shape, 0.25))
+            else:
+                node.register_parameter(parts[-1], nn.Parameter(torch.zeros(shape)))
+        self._ranges = {}
+        for pre in ("unet", "prior", "posterior", "fcomb"):
+            offs = [(off, int(np.prod(shape))) for name, shape, off, is_buf in table if not is_buf and name.startswith(pre + ".")]
+            self._ranges[pre] = (min(o for o, _ in offs), max(o + n for o, n in offs))
+        self._nparams = max(hi for _, hi in self._ranges.values())
+        if init:
+            _init_reference_order(self)
+
+    # ------------------------------------------------------------------ engine management
+    def _cfg_struct(self, H, W, max_batch, max_members):
+        cfg = L.PuConfig()
+        cfg.input_channels, cfg.num_classes, cfg.latent_dim = self.input_channels, self.num_classes, self.latent_dim
+        cfg.depth = len(self.num_filters)
+        for i, v in enumerate(self.num_filters): cfg.num_filters[i] = v
+        for i, v in enumerate(self.channel_mult): cfg.channel_mult[i] = v
+        cfg.model_channels = self.model_channels
+        cfg.H, cfg.W, cfg.max_batch, cfg.max_members = H, W, max_batch, max_members
+        cfg.dtype = L.DTYPES[self.compute_dtype]
+        cfg.dropout_p = self.dropout
+        return cfg
+
+    def _query_table(self):
+        """Ask the library for the reference-ordered parameter table (needs no GPU: planning only... but pu_create
+        allocates, so a tiny throw-away context is avoided by a pure-host table query when no device is present)."""
+        return _param_table_host(self)
+
+    def _owner_device(self):
+        return next(self.parameters()).device
+
+    def _ensure(self, H, W, B, M):
+        dev = self._owner_device()
+        if dev.type != "cuda":
+            raise L.ProbUNetLibraryError("ProbabilisticUNet parameters must live on a ROCm device (model.to('cuda')); "
+                                         "this engine has no CPU path")
+        mb = max(B, self._want_batch, self._ctx_key[2] if self._ctx_key else 0)
+        mm = max(M, self._want_members, self._ctx_key[3] if self._ctx_key else 0, 1)
+        key = (H, W, mb, mm, self.compute_dtype, dev.index or 0, self.dropout)
+        if self._ctx is not None and self._ctx_key == key:
+            self._check_views()
+            return
+        self._release()
+        cfg = self._cfg_struct(H, W, mb, mm)
+        ctx = C.c_void_p()
+        L.check(L.lib().pu_create(C.byref(cfg), dev.index or 0, C.byref(ctx)), None, "pu_create")
+        self._ctx, self._ctx_key = ctx, key
+        n = L.lib().pu_param_count(ctx)
+        if n != self._nparams:
+            raise L.ProbUNetLibraryError(f"parameter count mismatch: engine {n} vs host {self._nparams}")
+        self._flatten(dev)
+        L.check(L.lib().pu_bind_params(ctx, L.ptr(self._flat), L.ptr(self._engine_grads)), ctx, "pu_bind_params")
+
+    def _release(self):
+        if self._ctx is not None:
+            torch.cuda.synchronize()
+            L.lib().pu_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    def _flatten(self, dev):
+        """Make every nn.Parameter a view of one flat fp32 device buffer in the engine's order."""
+        if self._flat is None or self._flat.device != dev:
+            flat = torch.empty(self._nparams, device=dev, dtype=torch.float32)
+            self._engine_grads = torch.zeros(self._nparams, device=dev, dtype=torch.float32)
+            self._flat_grad = torch.zeros(self._nparams, device=dev, dtype=torch.float32)
+        else:
+            flat = self._flat
+        P = dict(self.named_parameters())
+        with torch.no_grad():
+            for name, shape, off, is_buf in self._table:
+                if is_buf:
+                    continue
+                p = P[name]
+                n = p.numel()
+                if p.data_ptr() != flat.data_ptr() + 4 * off:
+                    flat[off:off + n].copy_(p.data.reshape(-1).to(dev, torch.float32))
+                    p.data = flat[off:off + n].view(shape)
+        self._flat = flat
+        self._probe = [(P[name], off) for name, shape, off, is_buf in (self._table[1], self._table[len(self._table) // 2], self._table[-1]) if not is_buf]
+
+    def _check_views(self):
+        base = self._flat.data_ptr()
+        for p, off in self._probe:
+            if p.data_ptr() != base + 4 * off:
+                self._flatten(self._owner_device())
+                L.check(L.lib().pu_bind_params(self._ctx, L.ptr(self._flat), L.ptr(self._engine_grads)), self._ctx, "pu_bind_params")
+                return
+
+    def _anchor_t(self):
+        if self._anchor is None or self._anchor.device != self._owner_device():
+            self._anchor = torch.zeros(1, device=self._owner_device(), requires_grad=True)
+        return self._anchor
+
+    def _params_dirty(self):
+        L.lib().pu_params_changed(self._ctx)
+
+    def _deliver(self, g, lo, hi):
+        """Engine gradients [lo, hi) (x grad_output g) -> p.grad (accumulating like autograd does).
+        Under data parallelism the engine gradients are first averaged over the process group (RCCL all-reduce)."""
+        eg = self._engine_grads[lo:hi]
+        if self._dp_world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(eg, op=dist.ReduceOp.SUM, group=self._dp_group)
+            eg.mul_(1.0 / self._dp_world)
+        if g is not None:
+            eg = eg * g.reshape(())
+        P = self._params_in(lo, hi)
+        fresh = all(p.grad is None for p, _, _ in P)
+        if fresh:
+            self._flat_grad[lo:hi].copy_(eg)
+            for p, off, n in P:
+                p.grad = self._flat_grad[off:off + n].view(p.shape)
+        else:
+            for p, off, n in P:
+                ge = eg[off - lo:off - lo + n].view(p.shape)
+                if p.grad is None:
+                    p.grad = ge.clone()
+                else:
+                    p.grad.add_(ge)
+
+    def _params_in(self, lo, hi):
+        key = (lo, hi)
+        cache = self.__dict__.setdefault("_pin_cache", {})
+        if key not in cache:
+            P = dict(self.named_parameters())
+            cache[key] = [(P[name], off, int(np.prod(shape))) for name, shape, off, is_buf in self._table
+                          if not is_buf and lo <= off < hi]
+        return cache[key]
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self.__dict__.pop("_pin_cache", None)
+        self._anchor = None
+        return r
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        sd = dict(state_dict)
+        k = "posterior.encoder.0.weight"
+        if k in sd:
+            want = dict(self.named_parameters())[k].shape[1]
+            if sd[k].shape[1] != want:      # reference checkpoints carry 2*Cin planes; extra planes only ever saw zeros
+                sd[k] = sd[k][:, :want]
+        r = super().load_state_dict(sd, strict=strict, **kw)
+        if self._ctx is not None:
+            self._params_dirty()
+        return r
+
+    # ------------------------------------------------------------------ data parallel
+    def enable_data_parallel(self, process_group=None):
+        """One process per GPU; gradients are averaged with a torch.distributed all-reduce (backend 'nccl' == RCCL
+        over xGMI) on the flat gradient buffer before they reach p.grad.  Parameters are broadcast from rank 0."""
+        import torch.distributed as dist
+        self._dp_group = process_group
+        self._dp_world = dist.get_world_size(process_group)
+        if self._dp_world > 1:
+            for p in self.parameters():
+                dist.broadcast(p.data, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0, group=process_group)
+            if self._ctx is not None:
+                self._params_dirty()
+        return self
+
+    # ------------------------------------------------------------------ raw engine calls
+    def _prep(self, x):
+        if x.dim() != 4:
+            raise ValueError(f"expected [B, C, H, W], got {tuple(x.shape)}")
+        return x.contiguous().float()
+
+    def _unet_fwd(self, x):
+        x = self._prep(x)
+        B, Cc, H, W = x.shape
+        if Cc != self.input_channels:
+            raise ValueError(f"expected {self.input_channels} input planes, got {Cc}")
+        self._ensure(H, W, B, 1)
+        self._params_dirty()
+        feat = torch.empty(B, self.num_filters[0], H, W, device=x.device, dtype=torch.float32)
+        train = 1 if (self.training and self.dropout > 0) else 0
+        L.check(L.lib().pu_unet_fwd(self._ctx, L.ptr(x), L.ptr(feat), B, train, self._next_seed(), L.current_stream()), self._ctx, "pu_unet_fwd")
+        return feat
+
+    def _gauss_fwd(self, which, x, target):
+        x = self._prep(x)
+        B, Cc, H, W = x.shape
+        self._ensure(H, W, B, 1)
+        self._params_dirty()
+        if which == L.PU_POSTERIOR:
+            target = self._prep(target)
+            if target.shape[1] != self.num_classes:
+                if target.shape[1] == self.input_channels and self.num_classes < self.input_channels:
+                    target = target[:, : self.num_classes].contiguous()   # reference-style zero-padded target
+                else:
+                    raise ValueError(f"expected {self.num_classes} target planes, got {target.shape[1]}")
+        mu = torch.empty(B, self.latent_dim, device=x.device, dtype=torch.float32)
+        ls = torch.empty_like(mu)
+        L.check(L.lib().pu_gauss_fwd(self._ctx, which, L.ptr(x), L.ptr(target) if which == L.PU_POSTERIOR else None, L.ptr(mu), L.ptr(ls), B,
+                                     L.current_stream()), self._ctx, "pu_gauss_fwd")
+        self._last_mu[which] = mu
+        return mu, ls
+
+    def _fcomb_fwd(self, feat, z):
+        if feat.dim() != 4 or z.dim() != 2:
+            raise ValueError("fcomb(feature_map [B,F0,H,W], z [B,L])")
+        B, F0, H, W = feat.shape
+        if z.shape[0] != B or z.shape[1] != self.latent_dim or F0 != self.num_filters[0]:
+            raise ValueError(f"fcomb shape mismatch: feature_map {tuple(feat.shape)}, z {tuple(z.shape)}")
+        if feat.stride(0) == 0 and feat[0].is_contiguous():
+            src, bstride = feat[0], 0                      # expand()-ed view: one feature map broadcast to the batch
+        else:
+            src = feat.contiguous(); bstride = F0 * H * W
+        src = src.float()
+        self._ensure(H, W, B, 1)
+        self._params_dirty()
+        out = torch.empty(B, self.num_classes, H, W, device=feat.device, dtype=torch.float32)
+        L.check(L.lib().pu_fcomb_fwd(self._ctx, L.ptr(src), bstride, L.ptr(z.contiguous().float()), L.ptr(out), B, L.current_stream()),
+                self._ctx, "pu_fcomb_fwd")
+        return out
+
+    def _next_seed(self):
+        self._step += 1
+        return (torch.initial_seed() * 0x9E3779B97F4A7C15 + self._step * 0xD1B54A32D192ED03 + (self._dp_rank() << 48)) & 0xFFFFFFFFFFFFFFFF
+
+    def _dp_rank(self):
+        if self._dp_world > 1:
+            import torch.distributed as dist
+            return dist.get_rank(self._dp_group)
+        return 0
+
+    # ------------------------------------------------------------------ reference API
+    def forward(self, x, target=None, t=None, training=True):
+        """prob_unet.py:194-224.  `training` is an argument (independent of self.training); `t` is ignored."""
+        if not torch.is_grad_enabled():
+            use_post = bool(training) and target is not None
+            r = self.sample(x, 1, target=target if use_post else None, _return_dist=True)
+            out, dist_ = r
+            if use_post: self.posterior_latent_space = dist_
+            else: self.prior_latent_space = dist_
+            return out[:, 0]
+        unet_features = self.unet(x)
+        if training and target is not None:
+            self.posterior_latent_space = self.posterior(x, target)
+            z = self.posterior_latent_space.rsample()
+        else:
+            self.prior_latent_space = self.prior(x)
+            z = self.prior_latent_space.rsample()
+        return self.fcomb(unet_features, z)
+
+    def elbo(self, x, target, t=None, M: int = 5, alpha: float = 0.95, eps: Optional[torch.Tensor] = None):
+        """Fused ELBO forward(+backward when grad is enabled).
+
+        recon == "afcrps" (prob_unet.py:273-317; what train_prob_unet_model.py:133 unpacks):
+            returns (total_loss, [crps], kl_div[B])
+        recon == "l1" (prob_unet.py:325-381): returns (total_loss, [l1], kl_div[B], kl_div2[B])
+        eps: optional explicit reparameterisation noise [M, B, L] (default: torch.randn on the device generator).
+        """
+        x = self._prep(x); target = self._prep(target)
+        B, Cc, H, W = x.shape
+        if Cc != self.input_channels:
+            raise ValueError(f"expected {self.input_channels} input planes, got {Cc}")
+        if target.shape[1] != self.num_classes:
+            if target.shape[1] == self.input_channels and self.num_classes < self.input_channels:
+                target = target[:, : self.num_classes].contiguous()
+            else:
+                raise ValueError(f"expected {self.num_classes} target planes, got {target.shape[1]}")
+        afcrps = self.recon == "afcrps"
+        if afcrps and M < 2:
+            raise ValueError(f"M must be at least 2 to compute afCRPS but got M={M}")
+        Mx = M if afcrps else 1
+        self._ensure(H, W, B, Mx)
+        self._params_dirty()
+        if eps is None:
+            eps = torch.randn(Mx, B, self.latent_dim, device=x.device, dtype=torch.float32)
+        eps = eps.contiguous().float()
+        if tuple(eps.shape) != (Mx, B, self.latent_dim):
+            raise ValueError(f"eps must be [{Mx}, {B}, {self.latent_dim}]")
+        with_bwd = 1 if torch.is_grad_enabled() else 0
+        scal = torch.empty(L.PU_NUM_SCALARS, device=x.device, dtype=torch.float32)
+        klv = torch.empty(B, device=x.device, dtype=torch.float32)
+        kl2v = None if afcrps else torch.empty(B, device=x.device, dtype=torch.float32)
+        train = 1 if (self.training and self.dropout > 0) else 0
+        L.check(L.lib().pu_elbo_fwd_bwd(self._ctx, L.ptr(x), L.ptr(target), L.ptr(eps), B, Mx,
+                                        L.PU_RECON_AFCRPS if afcrps else L.PU_RECON_L1,
+                                        float(self.beta_0), float(self.beta_1), float(self.beta_2), float(alpha), train,
+                                        self._next_seed(), with_bwd, L.ptr(scal), L.ptr(klv), L.ptr(kl2v), L.current_stream()),
+                self._ctx, "pu_elbo_fwd_bwd")
+        total = scal[L.PU_S_TOTAL]
+        if with_bwd:
+            total = _DeliverGrads.apply(total, self._anchor_t(), self, 0, self._nparams)
+        recon = scal[L.PU_S_RECON]
+        recon_list = [recon.item()] if self.sync_scalars else [recon]
+        self._last_scalars = scal
+        if afcrps:
+            return total, recon_list, klv
+        return total, recon_list, klv, kl2v
+
+    @torch.no_grad()
+    def sample(self, x, n: int, target=None, eps: Optional[torch.Tensor] = None, _return_dist: bool = False):
+        """n samples per input with the U-Net and the latent encoder evaluated ONCE (the pattern of
+        latent_exploration.py:119-129; replaces the n x model(x, training=False) loop of
+        train_prob_unet_model.py:244-247).  Returns [B, n, Cout, H, W]."""
+        x = self._prep(x)
+        B, Cc, H, W = x.shape
+        self._ensure(H, W, B, n)
+        self._params_dirty()
+        if target is not None:
+            target = self._prep(target)
+            if target.shape[1] != self.num_classes:
+                target = target[:, : self.num_classes].contiguous()
+        if eps is None:
+            eps = torch.randn(n, B, self.latent_dim, device=x.device, dtype=torch.float32)
+        eps = eps.contiguous().float()
+        out = torch.empty(B, n, self.num_classes, H, W, device=x.device, dtype=torch.float32)
+        mu = torch.empty(B, self.latent_dim, device=x.device, dtype=torch.float32); sg = torch.empty_like(mu)
+        L.check(L.lib().pu_sample(self._ctx, L.ptr(x), L.ptr(target), L.ptr(eps), B, n, L.ptr(out), L.ptr(mu), L.ptr(sg), L.current_stream()),
+                self._ctx, "pu_sample")
+        if _return_dist:
+            return out, Independent(Normal(loc=mu, scale=sg), 1)
+        return out
+
+    @staticmethod
+    def reconstruct(residual, lrinterp, residual_std, epsilon: float = 1e-10):
+        """climex_utils.py:277-285 (`lrinterp_to_residuals` datasets): hr = lrinterp + residual * (std + eps)."""
+        return lrinterp + residual * (residual_std + epsilon)
+
+    def elbo_fwd_flops(self, B, M):
+        return L.lib().pu_elbo_fwd_flops(self._ctx, B, M) if self._ctx is not None else float("nan")
+
+
+# ----------------------------------------------------------------------------------------------- host-side table
+def _param_table_host(m: ProbabilisticUNet):
+    """The reference state_dict layout (names, shapes, flat offsets) — the host twin of build_plan() in
+    csrc/engine.hip; pu_param_count() is cross-checked against it when the engine is created and
+    tests/test_host_cpu.py compares it with the keys captured from the reference."""
+    out = []
+    off = 0
+
+    def add(name, shape, buf=False):
+        nonlocal off
+        shape = tuple(int(s) for s in shape)
+        if buf:
+            out.append((name, shape, -1, True))
+        else:
+            out.append((name, shape, off, False))
+            off += int(np.prod(shape))
+
+    mc, mult, D = m.model_channels, m.channel_mult, len(m.channel_mult)
+    emb = mc * 4
+    add("unet.map_label.weight", (emb, 1))
+
+    def block(p, cin, cout, up=False, down=False):
+        add(p + ".norm0.weight", (cin,)); add(p + ".norm0.bias", (cin,))
+        add(p + ".conv0.weight", (cout, cin, 3, 3)); add(p + ".conv0.bias", (cout,))
+        if up or down: add(p + ".conv0.resample_filter", (1, 1, 2, 2), True)
+        add(p + ".affine.weight", (2 * cout, emb)); add(p + ".affine.bias", (2 * cout,))
+        add(p + ".norm1.weight", (cout,)); add(p + ".norm1.bias", (cout,))
+        add(p + ".conv1.weight", (cout, cout, 3, 3)); add(p + ".conv1.bias", (cout,))
+        if cin != cout:
+            add(p + ".skip.weight", (cout, cin, 1, 1)); add(p + ".skip.bias", (cout,))
+            if up or down: add(p + ".skip.resample_filter", (1, 1, 2, 2), True)
+        elif up or down:
+            add(p + ".skip.resample_filter", (1, 1, 2, 2), True)
+
+    cout = m.input_channels
+    skips = []
+    for lv in range(D):
+        r = 128 >> lv
+        p = f"unet.enc.{r}x{r}"
+        if lv == 0:
+            cin, cout = cout, mc * mult[0]
+            add(p + "_conv.weight", (cout, cin, 3, 3)); add(p + "_conv.bias", (cout,))
+        else:
+            block(p + "_down", cout, cout, down=True)
+        skips.append(cout)
+        for i in range(2):
+            cin, cout = cout, mc * mult[lv]
+            block(p + f"_block{i}", cin, cout)
+            skips.append(cout)
+    for lv in reversed(range(D)):
+        r = 128 >> lv
+        p = f"unet.dec.{r}x{r}"
+        if lv == D - 1:
+            block(p + "_in0", cout, cout); block(p + "_in1", cout, cout)
+        else:
+            block(p + "_up", cout, cout, up=True)
+        for i in range(3):
+            cin = cout + skips.pop(); cout = mc * mult[lv]
+            block(p + f"_block{i}", cin, cout)
+    add("unet.out_norm.weight", (cout,)); add("unet.out_norm.bias", (cout,))
+    add("unet.out_conv.weight", (m.num_filters[0], cout, 3, 3)); add("unet.out_conv.bias", (m.num_filters[0],))
+    for net, cin0 in (("prior", m.input_channels), ("posterior", m.input_channels + m.num_classes)):
+        cin, idx = cin0, 0
+        for lv in range(D):
+            if lv: idx += 1
+            for _ in range(3):
+                add(f"{net}.encoder.{idx}.weight", (m.num_filters[lv], cin, 3, 3)); add(f"{net}.encoder.{idx}.bias", (m.num_filters[lv],))
+                cin = m.num_filters[lv]; idx += 2
+        add(f"{net}.conv_mu.weight", (m.latent_dim, m.num_filters[-1], 1, 1)); add(f"{net}.conv_mu.bias", (m.latent_dim,))
+        add(f"{net}.conv_log_sigma.weight", (m.latent_dim, m.num_filters[-1], 1, 1)); add(f"{net}.conv_log_sigma.bias", (m.latent_dim,))
+    f0 = m.num_filters[0]
+    add("fcomb.layers.0.weight", (f0, f0 + m.latent_dim, 1, 1)); add("fcomb.layers.0.bias", (f0,))
+    add("fcomb.layers.2.weight", (f0, f0, 1, 1)); add("fcomb.layers.2.bias", (f0,))
+    add("fcomb.layers.4.weight", (m.num_classes, f0, 1, 1)); add("fcomb.layers.4.bias", (m.num_classes,))
+    return out

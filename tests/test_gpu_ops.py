@@ -75,7 +75,7 @@ def test_groupnorm_silu_fwd_bwd(dt, rs, shape):
     y = torch.empty(B, Cc, OH, OW, device=dev); dx = torch.empty(B, Cc, H, W, device=dev)
     dg = torch.empty(Cc, device=dev); db = torch.empty(Cc, device=dev); dss = torch.empty(2 * Cc, device=dev)
     L.check(lib.pu_op_gnsilu(dt, rs, B, Cc, H, W, L.ptr(x.detach()), L.ptr(gamma.detach()), L.ptr(beta.detach()),
-                             L.ptr(ss.detach()) if adaptive else None, L.ptr(y), L.ptr(dy), L.ptr(dx), L.ptr(dg), L.ptr(db), L.ptr(dss), st),
+                             L.ptr(ss.detach()) if adaptive else None, L.ptr(y), L.ptr(dy), L.ptr(dx), L.ptr(dg), L.ptr(db), L.ptr(dss), 0.0, 0, st),
             None, "gnsilu")
     close(y, h.detach(), dt, "gn fwd")
     close(dx, x.grad, dt, "gn dx")
@@ -83,3 +83,32 @@ def test_groupnorm_silu_fwd_bwd(dt, rs, shape):
     close(db, beta.grad, dt, "gn dbeta")
     if adaptive:
         close(dss, ss.grad, dt, "gn dscale/shift")
+
+
+@pytest.mark.parametrize("dt", [L.PU_F32, L.PU_F16])
+def test_dropout_mask_statistics_and_backward(dt):
+    """UNetBlock dropout (networks.py:177): inverted dropout p=0.1 fused into GN+SiLU; the backward regenerates the
+    same counter-hash mask.  Checked by injecting the observed mask into a torch reference (SURVEY §7 RNG parity)."""
+    B, Cc, H, W, p = 2, 32, 32, 32, 0.1
+    dev = torch.device("cuda:0"); g = torch.Generator(device="cpu").manual_seed(5)
+    x = q(torch.randn(B, Cc, H, W, generator=g) + 2.0, dt).to(dev).requires_grad_(True)     # +2: silu output rarely exactly 0
+    gamma = (1 + 0.2 * torch.randn(Cc, generator=g)).to(dev).requires_grad_(True)
+    beta = (0.5 + 0.1 * torch.randn(Cc, generator=g)).to(dev).requires_grad_(True)
+    dy = q(torch.randn(B, Cc, H, W, generator=g), dt).to(dev)
+    lib = L.lib(); st = L.current_stream()
+    outs = []
+    for drop, seed in ((0.0, 0), (p, 123), (p, 124)):
+        y = torch.empty(B, Cc, H, W, device=dev); dx = torch.empty_like(y)
+        dg = torch.empty(Cc, device=dev); db = torch.empty(Cc, device=dev)
+        L.check(lib.pu_op_gnsilu(dt, 0, B, Cc, H, W, L.ptr(x.detach()), L.ptr(gamma.detach()), L.ptr(beta.detach()), None, L.ptr(y), L.ptr(dy),
+                                 L.ptr(dx), L.ptr(dg), L.ptr(db), None, drop, seed, st), None, "gnsilu")
+        outs.append((y, dx, dg, db))
+    y0, y1, y2 = outs[0][0], outs[1][0], outs[2][0]
+    mask = (y1 != 0).float()
+    frac = 1.0 - float(mask.mean())
+    assert 0.08 < frac < 0.12, frac
+    assert not torch.equal(y1 != 0, y2 != 0)                                   # different seed, different mask
+    close(y1, y0 * mask / (1 - p), dt, "kept elements scaled by 1/(1-p)")
+    h = F.silu(F.group_norm(x, 8, gamma, beta, 1e-5)) * mask / (1 - p)
+    h.backward(dy)
+    close(outs[1][1], x.grad, dt, "dropout dx"); close(outs[1][2], gamma.grad, dt, "dropout dgamma"); close(outs[1][3], beta.grad, dt, "dropout dbeta")
