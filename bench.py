@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Throughput bench for the MI355X Probabilistic U-Net engine.
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+Metric (BASELINE.json): field-pairs/sec of the ELBO forward+backward at 256x256.
+Workload at every N: BASELINE config 3/4 — 4->1 planes, 256x256, latent 12, depth-5 U-Net
+(num_filters [32..512], model_channels 32, channel_mult [1,2,4,8,16]), 32 field pairs per GPU (weak scaling),
+afCRPS-ELBO with M=5 posterior members, fp16 MFMA convolutions (fp32 accumulate, fp32 master weights),
+train mode (dropout 0.1), followed by the AdamW(lr=1e-4) step of the reference trainer
+(train_prob_unet_model.py:133-141) — the optimizer step and, for N > 1, the RCCL gradient all-reduce are INSIDE the
+timed region.  Synthetic ClimEx-shaped fields, inputs resident in HBM before timing starts.
+
+One JSON line is printed by rank 0 with the contract fields plus `roofline` (dominant kernel: the 3x3 implicit-GEMM
+MFMA convolution, timed live with HIP events on its launch stream through pu_profile_*) and, at N=1, `cpu_baseline`
+(the torch-CPU oracle on a bounded sample of the same workload, host cores of this box).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CFG3 = dict(input_channels=4, num_classes=1, latent_dim=12, num_filters=[32, 64, 128, 256, 512], model_channels=32,
+            channel_mult=[1, 2, 4, 8, 16], H=256, W=256, batch=32, M=5)
+PEAK = {"f16": 2.5e15, "bf16": 2.5e15, "f32": 157.3e12}     # dense MFMA peaks, MI355X_MICROARCH.md
+
+
+def synthetic_fields(B, cin, cout, H, W, seed, device):
+    """ClimEx-shaped pairs: lo-res planes = N(0,1) smoothed by a 16x block mean + nearest upsample
+    (mimics lrinterp, climex_utils.py:202-204); residual-like target."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    lo = torch.randn(B, cin, H // 16, W // 16, generator=g)
+    x = lo.repeat_interleave(16, 2).repeat_interleave(16, 3) + 0.1 * torch.randn(B, cin, H, W, generator=g)
+    y = x[:, :cout] * 0.5 + 0.5 * torch.randn(B, cout, H, W, generator=g)
+    return x.to(device), y.to(device)
+
+
+def perturb_zero_init(model, seed=7):
+    """The reference zero-initialises conv1 / out_conv (networks.py:154,297); give them small weights so that the
+    backward pass is numerically non-trivial. Same FLOPs either way."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    with torch.no_grad():
+        for k, p in model.named_parameters():
+            if k.endswith("conv1.weight") or k.endswith("out_conv.weight"):
+                fan_in = p[0].numel()
+                p.copy_((torch.randn(p.shape, generator=g) * (0.5 / fan_in ** 0.5)).to(p.device))
+
+
+def build_model(cfg, dtype, device):
+    import probunet_amd as pa
+    torch.manual_seed(42)
+    m = pa.ProbabilisticUNet(cfg["input_channels"], cfg["num_classes"], cfg["latent_dim"], cfg["num_filters"], cfg["model_channels"],
+                             cfg["channel_mult"], 1.0, 1.0, 0.0, dtype=dtype, max_batch=cfg["batch"], max_members=cfg["M"])
+    perturb_zero_init(m)
+    return m.to(device).train()
+
+
+def cpu_baseline(cfg, seconds_budget=25.0):
+    """The oracle (kind "port": torch-CPU fp32 restatement, validated against the reference's golden vectors) on a bounded
+    sample of the same workload: cfg3 shapes, M as in the bench, batch 1, fwd+bwd, dropout masks injected."""
+    from oracle import probunet_oracle as O
+    from tests.filler import fill_state
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    oc = O.Config(cfg["input_channels"], cfg["num_classes"], cfg["latent_dim"], cfg["num_filters"], cfg["model_channels"], cfg["channel_mult"])
+    P = fill_state(O.param_shapes(oc))
+    B = 1
+    x, y = synthetic_fields(B, cfg["input_channels"], cfg["num_classes"], cfg["H"], cfg["W"], 99, "cpu")
+    eps = torch.randn(cfg["M"], B, cfg["latent_dim"])
+    enc, dec = O.unet_layout(oc)
+    times = []
+    t_all = time.time()
+    for it in range(4):
+        masks = {}
+        for b in enc + dec:
+            if b.kind == "block":
+                lv = int(b.name.split(".")[2].split("x")[0])
+                r = cfg["H"] * lv // 128
+                masks[b.name] = (torch.rand(B, b.cout, r, r) >= oc.dropout).float()
+        t0 = time.time()
+        O.elbo_with_grads(P, oc, x, y, eps, beta0=1.0, beta1=1.0, drop_masks=masks)
+        dt = time.time() - t0
+        if it > 0:
+            times.append(dt)
+        if time.time() - t_all > seconds_budget and times:
+            break
+    med = sorted(times)[len(times) // 2]
+    return dict(value=B / med, unit="field-pairs/s", cores=cores, kind="port",
+                sample=f"cfg3 shapes (4->1, 256x256, depth 5, L=12, M={cfg['M']}), batch 1, fp32 torch-CPU oracle fwd+bwd, "
+                       f"{len(times)} timed step(s) after 1 warm-up, median {med:.2f} s/step")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16", "f32"])
+    ap.add_argument("--batch", type=int, default=CFG3["batch"])
+    ap.add_argument("--members", type=int, default=CFG3["M"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-optimizer", action="store_true", help="time ELBO fwd+bwd only (diagnostic; not the reported metric)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    cfg = dict(CFG3, batch=args.batch, M=args.members)
+    model = build_model(cfg, args.dtype, device)
+    model.sync_scalars = False                       # keep the loss scalars on the device: no .item() sync per step
+    if world > 1:
+        model.enable_data_parallel()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
+    x, y = synthetic_fields(cfg["batch"], cfg["input_channels"], cfg["num_classes"], cfg["H"], cfg["W"], 1234 + rank, device)
+    t_stamp = torch.zeros(cfg["batch"], 1, device=device)
+
+    def step():
+        loss, recon_list, kl_div = model.elbo(x, y, t_stamp, M=cfg["M"])        # train_prob_unet_model.py:133
+        opt.zero_grad()
+        loss.backward()
+        if not args.no_optimizer:
+            opt.step()
+        return loss
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    el = torch.tensor([elapsed], device=device, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    elapsed = float(el.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    pairs_per_s = world * cfg["batch"] * args.steps / elapsed
+    loss_val = float(loss.detach().item())
+
+    # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream (one extra step)
+    from probunet_amd import _lib as L
+    lib = L.lib()
+    roofline = None
+    fwd_flops = model.elbo_fwd_flops(cfg["batch"], cfg["M"])
+    if rank == 0:
+        lib.pu_profile_enable(1)
+        step(); torch.cuda.synchronize()
+        lib.pu_profile_enable(0)
+        ents = (L.PuProfEntry * 64)()
+        n = lib.pu_profile_collect(ents, 64)
+        rows = [dict(name=ents[i].name.decode(), launches=ents[i].launches, ms=ents[i].ms, flops=ents[i].flops, bytes=ents[i].bytes) for i in range(n)]
+        rows.sort(key=lambda r: -r["ms"])
+        if rows:
+            d = rows[0]
+            achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+            peak = PEAK[args.dtype] / 1e12
+            roofline = dict(bound="mfma", kernel=d["name"], achieved=round(achieved, 2), peak=peak, unit="TFLOP/s",
+                            frac=round(achieved / peak, 4), traffic=None, launches_per_step=d["launches"],
+                            avg_launch_us=round(1e3 * d["ms"] / d["launches"], 2),
+                            flops_per_launch=d["flops"] / d["launches"],
+                            algorithmic_bytes_per_launch=d["bytes"] / d["launches"],
+                            all_conv_kernels=[dict(name=r["name"], launches=r["launches"], ms=round(r["ms"], 3),
+                                                   tflops=round(r["flops"] / (r["ms"] * 1e-3) / 1e12, 2),
+                                                   algo_GBps=round(r["bytes"] / (r["ms"] * 1e-3) / 1e9, 1)) for r in rows],
+                            conv_ms_per_step=round(sum(r["ms"] for r in rows), 3))
+    out = dict(metric="field-pairs/sec (ELBO fwd+bwd) at 256x256", value=round(pairs_per_s, 3), unit="field-pairs/s",
+               n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 3), higher_is_better=True,
+               scaling="weak", vs_baseline=None, dtype=args.dtype, data="synthetic",
+               config=dict(workload=f"cfg3: 4->1 planes, 256x256, latent 12, depth-5 U-Net, {cfg['batch']} field pairs per GPU, "
+                                    f"afCRPS-ELBO M={cfg['M']} fwd+bwd, train mode (dropout 0.1)"
+                                    + ("" if args.no_optimizer else " + AdamW step") + (" + RCCL grad all-reduce" if world > 1 else ""),
+                           global_batch=world * cfg["batch"], parallelism=f"dp{world}",
+                           elbo_fwd_bwd_tflop_per_step=round(3 * fwd_flops / 1e12, 3),
+                           model_tflops=round(3 * fwd_flops * world / (elapsed / args.steps) / 1e12, 2), final_loss=loss_val),
+               roofline=roofline)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(cfg)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

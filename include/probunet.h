@@ -122,6 +122,12 @@ int64_t pu_workspace_bytes(pu_ctx*);
 /* conv + matmul FLOPs (2*MAC) of one ELBO forward for batch B, members M (BASELINE.md §2 counting). */
 double pu_elbo_fwd_flops(pu_ctx*, int B, int M);
 
+/* Per-kernel-class timing of the MFMA convolution launches (HIP events on the launch stream), for bench.py's roofline.
+ * pu_profile_enable(1) ... run steps ... pu_profile_collect() waits for the recorded events and returns entries. */
+typedef struct { char name[128]; long launches; double ms; double flops; double bytes; } pu_prof_entry;
+int pu_profile_enable(int on);
+int pu_profile_collect(pu_prof_entry* out, int max_entries);
+
 /* ---- single-op entry points (used by tests/ to pin each kernel against a torch fp32 reference) ----------- */
 /* 3x3 (ks=3) or 1x1 (ks=1) convolution on NCHW fp32 tensors through the engine's NHWC implicit-GEMM kernels in
  * `dtype`. mode 0: y = conv(x,w)+b (relu optional); 1: dx = dgrad(dy,w); 2: dw = wgrad(dy,x) (w/dw in [Cout,Cin,ks,ks]).

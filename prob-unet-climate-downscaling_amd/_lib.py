@@ -26,6 +26,10 @@ class PuParamDesc(C.Structure):
                 ("is_buffer", C.c_int32)]
 
 
+class PuProfEntry(C.Structure):
+    _fields_ = [("name", C.c_char * 128), ("launches", C.c_long), ("ms", C.c_double), ("flops", C.c_double), ("bytes", C.c_double)]
+
+
 class ProbUNetLibraryError(RuntimeError):
     pass
 
@@ -65,6 +69,8 @@ def lib():
     L.pu_elbo_fwd_bwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, f32, f32, f32, f32, i32, u64, i32, vp, vp, vp, vp]
     L.pu_sample.restype = i32; L.pu_sample.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp]
     L.pu_elbo_fwd_flops.restype = C.c_double; L.pu_elbo_fwd_flops.argtypes = [vp, i32, i32]
+    L.pu_profile_enable.restype = i32; L.pu_profile_enable.argtypes = [i32]
+    L.pu_profile_collect.restype = i32; L.pu_profile_collect.argtypes = [C.POINTER(PuProfEntry), i32]
     L.pu_op_conv.restype = i32
     L.pu_op_conv.argtypes = [i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]
     L.pu_op_gnsilu.restype = i32

@@ -639,6 +639,11 @@ int pu_param_table(pu_ctx* c, const pu_param_desc** out, int* n) {
   return PU_OK;
 }
 int64_t pu_param_count(pu_ctx* c) { return c ? c->nparams : -1; }
+int pu_profile_enable(int on) { prof_enable(on != 0); return PU_OK; }
+int pu_profile_collect(pu_prof_entry* out, int max_entries) {
+  static_assert(sizeof(pu_prof_entry) == sizeof(ProfEntry), "pu_prof_entry layout");
+  return out ? prof_collect(reinterpret_cast<ProfEntry*>(out), max_entries) : 0;
+}
 int64_t pu_workspace_bytes(pu_ctx* c) { return c ? (int64_t)(c->arena_size + (size_t)c->packed_elems * c->esz) : -1; }
 
 int pu_bind_params(pu_ctx* c, float* p, float* g) {

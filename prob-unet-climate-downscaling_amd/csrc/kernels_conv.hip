@@ -12,9 +12,46 @@
 //   D: col = l&31, row = (r&3) + 8(r>>2) + 4(l>>5)            (verified on hardware, scratch/mfma_probe.hip)
 // LDS tiles are [pixel][channel] / [cout][channel] with the channel (K) axis contiguous, so one ds_read_b128 yields
 // a whole 16-bit fragment; the 3x3 halo tile is staged once per 32-channel chunk and reused by all 9 taps.
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
 #include "pu_kernels.h"
 
 namespace pu {
+
+// ------------------------------------------------------------------ profiling hooks
+namespace {
+struct ProfRec { char name[128]; double flops, bytes; hipEvent_t e0, e1; };
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof_log;
+}  // namespace
+void prof_enable(bool on) { g_prof_on = on; }
+bool prof_enabled() { return g_prof_on; }
+void prof_record(const char* name, double flops, double bytes, hipStream_t s, bool begin) {
+  if (begin) {
+    ProfRec r; snprintf(r.name, sizeof r.name, "%s", name); r.flops = flops; r.bytes = bytes;
+    if (hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
+    (void)hipEventRecord(r.e0, s);
+    g_prof_log.push_back(r);
+  } else if (!g_prof_log.empty()) {
+    (void)hipEventRecord(g_prof_log.back().e1, s);
+  }
+}
+int prof_collect(ProfEntry* out, int max_entries) {
+  int n = 0;
+  for (auto& r : g_prof_log) {
+    float ms = 0.f;
+    if (hipEventSynchronize(r.e1) == hipSuccess) (void)hipEventElapsedTime(&ms, r.e0, r.e1);
+    (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
+    int i = 0;
+    for (; i < n; ++i) if (!strcmp(out[i].name, r.name)) break;
+    if (i == n) { if (n >= max_entries) continue; memset(&out[n], 0, sizeof(ProfEntry)); snprintf(out[n].name, sizeof out[n].name, "%s", r.name); ++n; }
+    out[i].launches += 1; out[i].ms += ms; out[i].flops += r.flops; out[i].bytes += r.bytes;
+  }
+  g_prof_log.clear();
+  return n;
+}
 
 // ------------------------------------------------------------------ MFMA traits
 template <typename T> struct MM;
@@ -213,7 +250,15 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
     attr_done = true;
   }
   dim3 grid((unsigned)((a.W / TW) * (a.H / TH) * a.B), (unsigned)cdiv(a.Cout, BN));
+  char tag[128];
+  const bool prof = prof_enabled();
+  if (prof) {
+    snprintf(tag, sizeof tag, "conv_igemm_kernel<%s,%d,%d,%d,%d,%d,%d>", sizeof(T) == 4 ? "f32" : (ET<T>::DT == 1 ? "f16" : "bf16"), KS, TH, TW, WM, WN, NTN);
+    const double px = (double)a.B * a.H * a.W;
+    prof_record(tag, 2.0 * px * a.Cout * (double)a.Cin * TAPS, px * (a.Cin + a.Cout) * sizeof(T) + (double)a.Cout * a.Cin * TAPS * sizeof(T), s, true);
+  }
   hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, a);
+  if (prof) prof_record(tag, 0, 0, s, false);
   return hipGetLastError();
 }
 
@@ -390,7 +435,15 @@ static hipError_t launch_wg(const WgradArgs& a, hipStream_t s) {
   int split = cdiv(1024, gy * gz);                       // ~4 blocks per CU
   if (split > ntiles) split = ntiles;
   if (split < 1) split = 1;
+  char tag[128];
+  const bool prof = prof_enabled();
+  if (prof) {
+    snprintf(tag, sizeof tag, "conv_wgrad_kernel<%s,%d,%d,%d>", sizeof(T) == 4 ? "f32" : (ET<T>::DT == 1 ? "f16" : "bf16"), KS, TH, TW);
+    const double px = (double)a.B * a.H * a.W;
+    prof_record(tag, 2.0 * px * a.Cout * (double)a.Cin * a.taps, px * (a.Cin + a.Cout) * sizeof(T) + (double)a.Cout * a.Cin * a.taps * 4, s, true);
+  }
   hipLaunchKernelGGL(kern, dim3(split, gy, gz), dim3(256), lds, s, a);
+  if (prof) prof_record(tag, 0, 0, s, false);
   return hipGetLastError();
 }
 

@@ -120,4 +120,13 @@ template <typename T> hipError_t launch_fcomb_bwd(const FcombBwdArgs&, hipStream
 
 hipError_t launch_fill(float* p, float v, long n, hipStream_t);
 
+// ---------------------------------------------------------------- optional per-kernel-class profiling (bench roofline)
+// When enabled, every MFMA conv launch is bracketed by HIP events on its own stream; prof_collect() sums elapsed time,
+// launches, algorithmic FLOPs and bytes per kernel instantiation (the names match rocprofv3's kernel names).
+struct ProfEntry { char name[128]; long launches; double ms; double flops; double bytes; };
+void prof_enable(bool on);
+bool prof_enabled();
+void prof_record(const char* name, double flops, double bytes, hipStream_t s, bool begin);
+int prof_collect(ProfEntry* out, int max_entries);   // syncs the recorded events; clears the log
+
 }  // namespace pu
