@@ -56,6 +56,9 @@ typedef struct {
   int32_t max_members;                 /* max M (ELBO ensemble) / max n (samples per input in pu_sample) */
   int32_t dtype;                       /* pu_dtype: arithmetic type of activations and MFMA operands */
   float   dropout_p;                   /* UNetBlock dropout (networks.py:239), applied when train != 0 */
+  float   grad_scale;                  /* static loss scale for the activation gradients of pu_elbo_fwd_bwd (removed again
+                                          from every parameter gradient); 0 = automatic: 1 for f32/bf16, a power of two
+                                          sized from B*M*C*H*W for f16 so that d(loss)/d(pred) ~ O(1) does not underflow */
 } pu_config;
 
 /* One state_dict entry of the reference (prob_unet.py / networks.py registration order). */

@@ -18,7 +18,8 @@ class PuConfig(C.Structure):
     _fields_ = [("input_channels", C.c_int32), ("num_classes", C.c_int32), ("latent_dim", C.c_int32), ("depth", C.c_int32),
                 ("num_filters", C.c_int32 * PU_MAX_LEVELS), ("model_channels", C.c_int32),
                 ("channel_mult", C.c_int32 * PU_MAX_LEVELS), ("H", C.c_int32), ("W", C.c_int32),
-                ("max_batch", C.c_int32), ("max_members", C.c_int32), ("dtype", C.c_int32), ("dropout_p", C.c_float)]
+                ("max_batch", C.c_int32), ("max_members", C.c_int32), ("dtype", C.c_int32), ("dropout_p", C.c_float),
+                ("grad_scale", C.c_float)]
 
 
 class PuParamDesc(C.Structure):

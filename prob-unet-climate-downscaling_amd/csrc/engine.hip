@@ -64,12 +64,14 @@ struct pu_ctx {
   GaussNet prior, post;
   int64_t fc_w0 = -1, fc_b0 = -1, fc_w1 = -1, fc_b1 = -1, fc_w2 = -1, fc_b2 = -1;
   // scratch
+  float* wg_slab = nullptr; long wg_slab_floats = 0;
   float* gn_part = nullptr; float* gn_part2 = nullptr; float* gn_coef2 = nullptr; float* bias_part = nullptr; TV dv_scratch;
   float *z = nullptr, *dz = nullptr, *preds = nullptr, *dpreds = nullptr, *kl = nullptr, *kl2 = nullptr, *scal = nullptr;
   Act fc_feat;                      // standalone fcomb input (converted) + its gradient
   float* fc_z = nullptr; int fc_B = 0; int fc_bcast = 0;
   int unet_B = 0, unet_train = 0; uint64_t unet_seed = 0;
   int max_gn_c = 0;
+  float inv_scale = 1.f;            // 1 / (loss scale) applied to every parameter-gradient write of the current backward
 };
 
 static std::string g_create_err;
@@ -344,6 +346,8 @@ static int build_plan(pu_ctx* c) {
   c->gn_part2 = alloc_f32(c, (size_t)mb * 64 * c->max_gn_c * 2);
   c->gn_coef2 = alloc_f32(c, (size_t)mb * c->max_gn_c * 3);
   c->bias_part = alloc_f32(c, (size_t)256 * 1024);
+  c->wg_slab_floats = c->dt == PU_F32 ? 0 : 32L * 1024 * 1024;
+  c->wg_slab = c->wg_slab_floats ? alloc_f32(c, (size_t)c->wg_slab_floats) : nullptr;
   {  // dv scratch: the largest GroupNorm input
     size_t mx = 0;
     auto upd = [&](const Block& b) { if (b.is_block) { size_t a = (size_t)b.x.v.H * b.x.v.W * b.x.v.C, q = (size_t)b.c0.v.H * b.c0.v.W * b.c0.v.C; if (a > mx) mx = a; if (q > mx) mx = q; } };
@@ -409,6 +413,7 @@ static int conv_wgrad(pu_ctx* c, const ConvL& L, TV dy, TV in, int B, hipStream_
   WgradArgs a; memset(&a, 0, sizeof a);
   a.dy = dy.p; a.dy_ld = dy.ld; a.Cout = L.cout; a.in = in.p; a.in_ld = in.ld; a.Cin = L.cin;
   a.dw = G(c, L.w_off); a.B = B; a.H = dy.H; a.W = dy.W; a.taps = L.ks * L.ks;
+  a.slab = c->wg_slab; a.slab_floats = c->wg_slab_floats; a.inv_scale = c->inv_scale;
   CKH(launch_wgrad<T>(a, s));
   return PU_OK;
 }
@@ -416,7 +421,7 @@ static int bias_chunks(long npix) { long n = npix / 256; if (n < 1) n = 1; if (n
 template <typename T>
 static int conv_bgrad(pu_ctx* c, TV dy, int B, float* d0, float* d1, hipStream_t s) {
   TV t = with_b(dy, B);
-  CKH(launch_bias_grad<T>(t, d0, d1, c->bias_part, bias_chunks((long)B * dy.H * dy.W), s));
+  CKH(launch_bias_grad<T>(t, d0, d1, c->bias_part, bias_chunks((long)B * dy.H * dy.W), c->inv_scale, s));
   return PU_OK;
 }
 
@@ -445,7 +450,7 @@ static int gn_bwd(pu_ctx* c, const GNL& n, TV x, TV y, TV dy, TV dx, int accumul
   a.dx = with_b(dx, B); a.accumulate = accumulate;
   a.dgamma = G(c, n.g_off); a.dbeta = G(c, n.b_off);
   a.dscale = n.ss_off >= 0 ? G(c, n.ss_off) : nullptr; a.dshift = n.ss_off >= 0 ? G(c, n.ss_off + n.C) : nullptr;
-  a.part2 = c->gn_part2; a.coef2 = c->gn_coef2;
+  a.part2 = c->gn_part2; a.coef2 = c->gn_coef2; a.inv_scale = c->inv_scale;
   CKH(launch_gn_bwd<T>(a, s));
   return PU_OK;
 }
@@ -560,7 +565,7 @@ static int gauss_backward(pu_ctx* c, GaussNet& g, hipStream_t s) {
   if (B <= 0) FAIL(PU_ERR_STATE, "Gaussian-encoder backward without a forward");
   TV lastg = with_b(g.outs.back().g, B);
   CKH(launch_heads_bwd<T>(with_b(g.outs.back().v, B), lastg, g.hbuf, P(c, g.wmu), P(c, g.wls), g.dmu, g.dls, L,
-                          G(c, g.wmu), G(c, g.bmu), G(c, g.wls), G(c, g.bls), s));
+                          G(c, g.wmu), G(c, g.bmu), G(c, g.wls), G(c, g.bls), c->inv_scale, s));
   for (int i = (int)g.convs.size() - 1; i >= 0; --i) {
     TV dy = with_b(g.outs[i].g, B);
     CKH(launch_relu_bwd<T>(with_b(g.outs[i].v, B), dy, s));
@@ -697,6 +702,7 @@ int pu_unet_bwd(pu_ctx* c, const float* dfeat, void* stream) {
   return dispatch(c, [&](auto t) -> int {
     typedef decltype(t) T;
     const int B = c->unet_B; if (B <= 0) FAIL(PU_ERR_STATE, "pu_unet_bwd without pu_unet_fwd");
+    c->inv_scale = 1.f;
     const int F = c->cfg.num_filters[0]; const long HW = (long)c->cfg.H * c->cfg.W;
     CKH(launch_nchw_to_nhwc<T>(dfeat, (long)F * HW, F, nullptr, 0, with_b(c->feat.g, B), s));
     return unet_backward<T>(c, s);
@@ -733,6 +739,7 @@ int pu_gauss_bwd(pu_ctx* c, int which, const float* dmu, const float* dls, void*
   hipStream_t s = (hipStream_t)stream;
   GaussNet& g = which == PU_PRIOR ? c->prior : c->post;
   if (g.lastB <= 0) FAIL(PU_ERR_STATE, "pu_gauss_bwd without pu_gauss_fwd");
+  c->inv_scale = 1.f;
   const size_t n = (size_t)g.lastB * c->cfg.latent_dim * sizeof(float);
   CKH(hipMemcpyAsync(g.dmu, dmu, n, hipMemcpyDeviceToDevice, s));
   CKH(hipMemcpyAsync(g.dls, dls, n, hipMemcpyDeviceToDevice, s));
@@ -770,7 +777,7 @@ int pu_fcomb_bwd(pu_ctx* c, const float* dout, float* dfeat, float* dz, void* st
     FcombBwdArgs a; memset(&a, 0, sizeof a);
     a.f = fcomb_args(c, fv, c->fc_bcast, c->fc_z, B, 1, nullptr);
     a.dout = dout; a.dfeat = with_b(c->fc_feat.g, B); a.dfeat_accumulate = 0; if (!dfeat) a.dfeat.p = nullptr;
-    a.dz = dz;
+    a.dz = dz; a.inv_scale = 1.f;
     a.dw0 = G(c, c->fc_w0); a.db0 = G(c, c->fc_b0); a.dw1 = G(c, c->fc_w1); a.db1 = G(c, c->fc_b1); a.dw2 = G(c, c->fc_w2); a.db2 = G(c, c->fc_b2);
     CKH(launch_fcomb_bwd<T>(a, s));
     if (dfeat) CKH(launch_nhwc_to_nchw<T>(with_b(c->fc_feat.g, B), F, dfeat, 0, s));
@@ -793,6 +800,15 @@ int pu_elbo_fwd_bwd(pu_ctx* c, const float* x, const float* target, const float*
   const long HW = (long)cf.H * cf.W; const int L = cf.latent_dim, Co = cf.num_classes, ci = cf.input_channels;
   const bool l1 = recon_kind == PU_RECON_L1;
   const int Mf = l1 ? 1 : M;
+  // static loss scale (see pu_config.grad_scale)
+  float S = cf.grad_scale > 0.f ? cf.grad_scale : 1.f;
+  if (cf.grad_scale <= 0.f && c->dt == PU_F16) {
+    const double norm = l1 ? 1.0 / ((double)B * Co * HW) : 1.0 / ((double)B * M * (M - 1) * Co * HW);
+    const double want = 1.0 / (2.0 * fmax(fabs((double)beta0), 1e-6) * norm * (l1 ? 1.0 : (double)(M - 1)));
+    int e2 = (int)floor(log2(fmax(want, 1.0))); if (e2 > 24) e2 = 24;
+    S = (float)ldexp(1.0, e2);
+  }
+  c->inv_scale = 1.f / S;
   return dispatch(c, [&](auto t) -> int {
     typedef decltype(t) T;
     int q;
@@ -808,7 +824,7 @@ int pu_elbo_fwd_bwd(pu_ctx* c, const float* x, const float* target, const float*
     CKH(launch_latent_fwd(la, s));
     FcombArgs fa = fcomb_args(c, with_b(c->feat.v, B), 0, c->z, B, Mf, c->preds);
     CKH(launch_fcomb_fwd<T>(fa, s));
-    CKH(launch_recon(recon_kind, c->preds, target, with_backward ? c->dpreds : nullptr, c->scal, B, Mf, Co, HW, alpha, beta0, s));
+    CKH(launch_recon(recon_kind, c->preds, target, with_backward ? c->dpreds : nullptr, c->scal, B, Mf, Co, HW, alpha, beta0 * S, s));
     CKH(launch_finish_scalars(c->scal, beta0, beta1, beta2, l1 ? 1 : 0, s));
     if (out_scalars) CKH(hipMemcpyAsync(out_scalars, c->scal, PU_NUM_SCALARS * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (out_kl) CKH(hipMemcpyAsync(out_kl, c->kl, (size_t)B * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -819,9 +835,10 @@ int pu_elbo_fwd_bwd(pu_ctx* c, const float* x, const float* target, const float*
     FcombBwdArgs fb; memset(&fb, 0, sizeof fb);
     fb.f = fa; fb.dout = c->dpreds; fb.dfeat = with_b(c->feat.g, B); fb.dfeat_accumulate = 0; fb.dz = c->dz;
     fb.dw0 = G(c, c->fc_w0); fb.db0 = G(c, c->fc_b0); fb.dw1 = G(c, c->fc_w1); fb.db1 = G(c, c->fc_b1); fb.dw2 = G(c, c->fc_w2); fb.db2 = G(c, c->fc_b2);
+    fb.inv_scale = c->inv_scale;
     CKH(launch_fcomb_bwd<T>(fb, s));
     LatentBwdArgs lb; memset(&lb, 0, sizeof lb);
-    lb.f = la; lb.dz = c->dz; lb.beta1 = beta1; lb.beta2 = l1 ? beta2 : 0.f;
+    lb.f = la; lb.dz = c->dz; lb.beta1 = beta1 * S; lb.beta2 = l1 ? beta2 * S : 0.f;
     lb.dmu_q = c->post.dmu; lb.dls_q = c->post.dls; lb.dmu_p = c->prior.dmu; lb.dls_p = c->prior.dls;
     CKH(launch_latent_bwd(lb, s));
     if ((q = gauss_backward<T>(c, c->post, s))) return q;
@@ -909,6 +926,8 @@ static int op_conv_t(int mode, int ks, int relu, int B, int Cin, int Cout, int H
     CK0(hipMemsetAsync(out, 0, (size_t)Cout * Cin * taps * sizeof(float), s));
     WgradArgs a; memset(&a, 0, sizeof a);
     a.dy = yb; a.dy_ld = cout_a; a.Cout = Cout; a.in = xin; a.in_ld = cin_a; a.Cin = Cin; a.dw = out; a.B = B; a.H = H; a.W = W; a.taps = taps;
+    a.inv_scale = 1.f;
+    if (sizeof(T) == 2) { a.slab_floats = 16L * 1024 * 1024; CK0(hipMalloc(&dwtmp, a.slab_floats * sizeof(float))); a.slab = dwtmp; }
     CK0(launch_wgrad<T>(a, s));
   }
   CK0(hipStreamSynchronize(s));
@@ -955,7 +974,7 @@ static int op_gn_t(int resample, int B, int C, int H, int W, const float* x, con
     memset(&bw, 0, sizeof bw);
     bw.f = a; bw.dy = tdy; bw.dv = tdv; bw.dx = tdx; bw.accumulate = 0;
     bw.dgamma = dgamma; bw.dbeta = dbeta; bw.dscale = ss ? dss : nullptr; bw.dshift = ss ? dss + C : nullptr;
-    bw.part2 = a.coef + (size_t)B * C * 2; bw.coef2 = bw.part2 + (size_t)B * nchunk * C * 2;
+    bw.part2 = a.coef + (size_t)B * C * 2; bw.coef2 = bw.part2 + (size_t)B * nchunk * C * 2; bw.inv_scale = 1.f;
     CK0(hipMemsetAsync(dgamma, 0, C * sizeof(float), s)); CK0(hipMemsetAsync(dbeta, 0, C * sizeof(float), s));
     if (ss) CK0(hipMemsetAsync(dss, 0, 2 * C * sizeof(float), s));
     CK0(launch_gn_bwd<T>(bw, s));

@@ -413,7 +413,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int co = co0 + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
-        if (co < a.Cout && ci < a.Cin) atomicAdd(a.dw + ((size_t)co * a.Cin + ci) * TAPS + t, acc[j][r]);
+        if (co < a.Cout && ci < a.Cin) atomicAdd(a.dw + ((size_t)co * a.Cin + ci) * TAPS + t, acc[j][r] * a.inv_scale);
       }
     }
   }
@@ -457,9 +457,13 @@ static hipError_t launch_wg_ks(const WgradArgs& a, hipStream_t s) {
 
 template <typename T>
 hipError_t launch_wgrad(const WgradArgs& a, hipStream_t s) {
-  if (a.taps == 9) return launch_wg_ks<T, 3>(a, s);
-  if (a.taps == 1) return launch_wg_ks<T, 1>(a, s);
-  return hipErrorInvalidValue;
+  if constexpr (sizeof(T) == 2) {
+    return launch_wgrad16<T>(a, s);                 // kernels_wgrad.hip
+  } else {
+    if (a.taps == 9) return launch_wg_ks<T, 3>(a, s);
+    if (a.taps == 1) return launch_wg_ks<T, 1>(a, s);
+    return hipErrorInvalidValue;
+  }
 }
 template hipError_t launch_wgrad<float>(const WgradArgs&, hipStream_t);
 template hipError_t launch_wgrad<f16>(const WgradArgs&, hipStream_t);

@@ -334,6 +334,7 @@ __global__ void gn_param_grad_kernel(GNBwdArgs a) {
   float S1 = 0.f, S2 = 0.f;
   for (int b = 0; b < f.x.B; ++b) { const float* pp = a.part2 + (((long)b * f.nchunk) * C + c) * 2; S1 += pp[0]; S2 += pp[1]; }
   const float s = f.scale ? f.scale[c] : 0.f;
+  S1 *= a.inv_scale; S2 *= a.inv_scale;
   a.dgamma[c] += (1.f + s) * S2;
   a.dbeta[c] += (1.f + s) * S1;
   if (a.dscale) a.dscale[c] += f.gamma[c] * S2 + f.beta[c] * S1;
@@ -547,18 +548,27 @@ hipError_t launch_relu_bwd(TV y, TV dy, hipStream_t s) {
   return hipGetLastError();
 }
 
-__global__ void bias_grad_finalize_kernel(const float* __restrict__ part, int nchunk, int C, float* d0, float* d1) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ __launch_bounds__(256) void bias_grad_finalize_kernel(const float* __restrict__ part, int nchunk, int C, float* d0, float* d1, float inv_scale) {
+  // 32 channels per block, 8 chunk lanes per channel
+  __shared__ float red[8][33];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), lane = threadIdx.x >> 5;
   float s = 0.f;
-  for (int k = 0; k < nchunk; ++k) s += part[(long)k * C + c];
-  d0[c] += s;
-  if (d1) d1[c] += s;
+  if (c < C) for (int k = lane; k < nchunk; k += 8) s += part[(long)k * C + c];
+  red[lane][threadIdx.x & 31] = s;
+  __syncthreads();
+  if (lane == 0 && c < C) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x & 31];
+    t *= inv_scale;
+    d0[c] += t;
+    if (d1) d1[c] += t;
+  }
 }
 template <typename T>
-hipError_t launch_bias_grad(TV dy, float* d0, float* d1, float* part, int nchunk, hipStream_t s) {
+hipError_t launch_bias_grad(TV dy, float* d0, float* d1, float* part, int nchunk, float inv_scale, hipStream_t s) {
   hipLaunchKernelGGL((chan_partial_kernel<T, false>), dim3(nchunk, 1), dim3(256), 0, s, dy, part, nchunk, 0);
-  hipLaunchKernelGGL(bias_grad_finalize_kernel, dim3(cdiv(dy.C, 256)), dim3(256), 0, s, part, nchunk, dy.C, d0, d1);
+  hipLaunchKernelGGL(bias_grad_finalize_kernel, dim3(cdiv(dy.C, 32)), dim3(256), 0, s, part, nchunk, dy.C, d0, d1, inv_scale);
   return hipGetLastError();
 }
 
@@ -631,7 +641,7 @@ __global__ __launch_bounds__(256) void heads_bwd_dx_kernel(TV dx, const float* _
   }
 }
 __global__ void heads_bwd_param_kernel(const float* __restrict__ hbuf, const float* __restrict__ dmu, const float* __restrict__ dls,
-                                       int B, int L, int C, float* dwmu, float* dbmu, float* dwls, float* dbls) {
+                                       int B, int L, int C, float* dwmu, float* dbmu, float* dwls, float* dbls, float inv_scale) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= L * C) return;
   const int l = i / C, c = i % C;
@@ -641,16 +651,16 @@ __global__ void heads_bwd_param_kernel(const float* __restrict__ hbuf, const flo
     a += dmu[(long)b * L + l] * h; q += dls[(long)b * L + l] * h;
     sa += dmu[(long)b * L + l]; sq += dls[(long)b * L + l];
   }
-  dwmu[i] += a; dwls[i] += q;
-  if (c == 0) { dbmu[l] += sa; dbls[l] += sq; }
+  dwmu[i] += a * inv_scale; dwls[i] += q * inv_scale;
+  if (c == 0) { dbmu[l] += sa * inv_scale; dbls[l] += sq * inv_scale; }
 }
 template <typename T>
 hipError_t launch_heads_bwd(TV xs, TV dx, const float* hbuf, const float* wmu, const float* wls, const float* dmu, const float* dls,
-                            int L, float* dwmu, float* dbmu, float* dwls, float* dbls, hipStream_t s) {
+                            int L, float* dwmu, float* dbmu, float* dwls, float* dbls, float inv_scale, hipStream_t s) {
   const long HW = (long)dx.H * dx.W;
   const int nchunk = (int)min((long)64, (HW * (dx.C / ET<T>::VEC) + 255) / 256);
   hipLaunchKernelGGL(heads_bwd_dx_kernel<T>, dim3(nchunk, dx.B), dim3(256), 0, s, dx, wmu, wls, dmu, dls, L, nchunk);
-  hipLaunchKernelGGL(heads_bwd_param_kernel, dim3(cdiv((long)L * dx.C, 256)), dim3(256), 0, s, hbuf, dmu, dls, dx.B, L, dx.C, dwmu, dbmu, dwls, dbls);
+  hipLaunchKernelGGL(heads_bwd_param_kernel, dim3(cdiv((long)L * dx.C, 256)), dim3(256), 0, s, hbuf, dmu, dls, dx.B, L, dx.C, dwmu, dbmu, dwls, dbls, inv_scale);
   (void)xs;
   return hipGetLastError();
 }
@@ -814,11 +824,11 @@ hipError_t launch_fill(float* p, float v, long n, hipStream_t s) {
   template hipError_t launch_maxpool<T>(TV, TV, hipStream_t);                                                        \
   template hipError_t launch_maxpool_bwd<T>(TV, TV, TV, hipStream_t);                                                \
   template hipError_t launch_relu_bwd<T>(TV, TV, hipStream_t);                                                       \
-  template hipError_t launch_bias_grad<T>(TV, float*, float*, float*, int, hipStream_t);                             \
+  template hipError_t launch_bias_grad<T>(TV, float*, float*, float*, int, float, hipStream_t);                             \
   template hipError_t launch_heads_fwd<T>(TV, const float*, const float*, const float*, const float*, int, float*,   \
                                           float*, float*, hipStream_t);                                              \
   template hipError_t launch_heads_bwd<T>(TV, TV, const float*, const float*, const float*, const float*,            \
-                                          const float*, int, float*, float*, float*, float*, hipStream_t);
+                                          const float*, int, float*, float*, float*, float*, float, hipStream_t);
 PU_INST(float)
 PU_INST(f16)
 PU_INST(bf16)

@@ -196,32 +196,358 @@ __global__ __launch_bounds__(256) void fcomb_bwd_kernel(FcombBwdArgs a, const fl
   if (tid < NE) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      atomicAdd(a.dw0 + (long)eo * WS + ec + e, aw0[e]);
-      atomicAdd(a.dw1 + (long)eo * F + ec + e, aw1[e]);
-      if (eo < f.Cout) atomicAdd(a.dw2 + (long)eo * F + ec + e, aw2[e]);
+      atomicAdd(a.dw0 + (long)eo * WS + ec + e, aw0[e] * a.inv_scale);
+      atomicAdd(a.dw1 + (long)eo * F + ec + e, aw1[e] * a.inv_scale);
+      if (eo < f.Cout) atomicAdd(a.dw2 + (long)eo * F + ec + e, aw2[e] * a.inv_scale);
     }
   }
   if (tid >= 128 && tid - 128 < F) {
-    atomicAdd(a.db1 + (tid - 128), ab1);
-    if (tid - 128 < f.Cout) atomicAdd(a.db2 + (tid - 128), ab2);
+    atomicAdd(a.db1 + (tid - 128), ab1 * a.inv_scale);
+    if (tid - 128 < f.Cout) atomicAdd(a.db2 + (tid - 128), ab2 * a.inv_scale);
+  }
+}
+
+
+// ------------------------------------------------------------------ 16-bit MFMA Fcomb (F = 32): forward and backward
+// Every per-pixel 32x32 mat-vec is an MFMA with the PIXEL on the lane: D[row = channel][col = pixel] = W . X.
+// The accumulator of one product is the B operand of the next without touching LDS (cdna_hip_programming.md §3,
+// "An accumulator tile as the next MFMA's operand"): registers 8s..8s+7 of lane (pixel, h) hold channels
+//     perm(s, h, e) = 16 s + 8 (e >> 2) + 4 h + (e & 3),      e = 0..7
+// so the constant A fragments of the chained products are preloaded with that K permutation.
+// The weight-gradient products sum over pixels (the lane axis), so their operands make one round trip through LDS as
+// [pixel][32] tiles (16-byte chunks XOR-swizzled by (pixel >> 2) & 3) and come back through ds_read_b64_tr_b16.
+typedef short fc_s4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) fc_s4* fc_lds_s4_ptr;
+template <typename T> struct FCM;
+template <> struct FCM<f16> {
+  typedef f16x8 Frag;
+  __device__ static __forceinline__ f32x16 mfma(Frag a, Frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+  __device__ static __forceinline__ void set(Frag& f, int e, float v) { f[e] = (_Float16)v; }
+};
+template <> struct FCM<bf16> {
+  typedef bf16x8 Frag;
+  __device__ static __forceinline__ f32x16 mfma(Frag a, Frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+  __device__ static __forceinline__ void set(Frag& f, int e, float v) { union { uint16_t u; __bf16 b; } x; x.u = f_to_bf16(v); f[e] = x.b; }
+};
+template <typename T> __device__ __forceinline__ typename FCM<T>::Frag fc_zero_frag() {
+  typename FCM<T>::Frag f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) FCM<T>::set(f, e, 0.f);
+  return f;
+}
+// registers 8s..8s+7 of an accumulator -> fragment of k-step s (chained product)
+template <typename T> __device__ __forceinline__ typename FCM<T>::Frag fc_acc_frag(const f32x16& a, int s) {
+  typename FCM<T>::Frag f;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) FCM<T>::set(f, e, a[8 * s + e]);
+  return f;
+}
+__device__ __forceinline__ int fc_perm(int s, int h, int e) { return 16 * s + 8 * (e >> 2) + 4 * h + (e & 3); }
+__device__ __forceinline__ int fc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+template <typename Frag>
+__device__ __forceinline__ Frag fc_tr_frag(const uint16_t* p0, const uint16_t* p1) {
+  union { fc_s4 h[2]; Frag f; } u;
+  u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((fc_lds_s4_ptr)(p0));
+  u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((fc_lds_s4_ptr)(p1));
+  return u.f;
+}
+// accumulator tile (rows = channel, col = pixel j) -> LDS tile [pixel][32], swizzled 16-byte chunks
+template <typename T>
+__device__ __forceinline__ void fc_store_tile(uint16_t* tile, int pix, int h, const f32x16& a) {
+#pragma unroll
+  for (int g4 = 0; g4 < 4; ++g4) {
+    float v[4] = {a[4 * g4], a[4 * g4 + 1], a[4 * g4 + 2], a[4 * g4 + 3]};
+    uint2 w;
+    if (ET<T>::DT == 1) {
+      union { f16 hh[4]; uint2 u; } x;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x.hh[e] = (f16)v[e];
+      w = x.u;
+    } else {
+      w.x = (uint32_t)f_to_bf16(v[0]) | ((uint32_t)f_to_bf16(v[1]) << 16); w.y = (uint32_t)f_to_bf16(v[2]) | ((uint32_t)f_to_bf16(v[3]) << 16);
+    }
+    *reinterpret_cast<uint2*>(tile + pix * 32 + ((g4 ^ ((pix >> 2) & 3)) * 8) + 4 * h) = w;
+  }
+}
+
+template <typename T> struct FcW {      // constant weight fragments of one lane
+  typename FCM<T>::Frag w0n[2];         // P1: A[o][c] natural k            (pre = W0f . feat)
+  typename FCM<T>::Frag w1p[2];         // P2: A[o][perm]                    (y1  = W1 . h0)
+  typename FCM<T>::Frag w2p[2];         // P3: A[co][perm], rows >= Cout 0   (out = W2 . h1)
+};
+template <typename T>
+__device__ __forceinline__ void fc_load_fwd_weights(const FcombArgs& f, int l, FcW<T>& w) {
+  const int i = l & 31, h = l >> 5, WS = 32 + f.L;
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      FCM<T>::set(w.w0n[s], e, f.w0[i * WS + 16 * s + 8 * h + e]);
+      FCM<T>::set(w.w1p[s], e, f.w1[i * 32 + fc_perm(s, h, e)]);
+      FCM<T>::set(w.w2p[s], e, i < f.Cout ? f.w2[i * 32 + fc_perm(s, h, e)] : 0.f);
+    }
+}
+
+// forward chain for one 32-pixel column tile; fb0/fb1: feat fragments (natural k). Returns h0, h1 (post-ReLU), y (out rows)
+template <typename T>
+__device__ __forceinline__ void fc_forward_tile(const FcW<T>& w, const typename FCM<T>::Frag* fb, const float* zb16, const float* b1_16,
+                                                f32x16& h0, f32x16& h1) {
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = zb16[r];                 // bias as the initial accumulator
+  acc = FCM<T>::mfma(w.w0n[0], fb[0], acc);
+  acc = FCM<T>::mfma(w.w0n[1], fb[1], acc);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) h0[r] = fmaxf(acc[r], 0.f);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = b1_16[r];
+  acc = FCM<T>::mfma(w.w1p[0], fc_acc_frag<T>(h0, 0), acc);
+  acc = FCM<T>::mfma(w.w1p[1], fc_acc_frag<T>(h0, 1), acc);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) h1[r] = fmaxf(acc[r], 0.f);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void fcomb_fwd16_kernel(FcombArgs f, const float* __restrict__ zb) {
+  typedef FCM<T> M;
+  const long HW = (long)f.feat.H * f.feat.W;
+  const int b = blockIdx.y, l = threadIdx.x & 63, wave = threadIdx.x >> 6, j = l & 31, h = l >> 5;
+  const uint16_t* fp = reinterpret_cast<const uint16_t*>(f.feat.p) + (f.bcast ? 0 : (long)b * HW * f.feat.ld);
+  FcW<T> w; fc_load_fwd_weights<T>(f, l, w);
+  float b1r[16], b2r[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { b1r[r] = f.b1[fc_row(r, h)]; b2r[r] = fc_row(r, h) < f.Cout ? f.b2[fc_row(r, h)] : 0.f; }
+  const long ntile = (HW + 31) / 32;
+  for (long t = (long)blockIdx.x * 4 + wave; t < ntile; t += (long)gridDim.x * 4) {
+    const long pix = t * 32 + j;
+    const bool valid = pix < HW;
+    typename M::Frag fb[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      union { V16 v; typename M::Frag fr; } u; u.v = zero16();
+      if (valid) u.v = *reinterpret_cast<const V16*>(fp + pix * f.feat.ld + 16 * s + 8 * h);
+      fb[s] = u.fr;
+    }
+    // the W0f . feat product is shared by all members: keep it, add the member's z-bias afterwards
+    f32x16 pre;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pre[r] = 0.f;
+    pre = M::mfma(w.w0n[0], fb[0], pre);
+    pre = M::mfma(w.w0n[1], fb[1], pre);
+    for (int m = 0; m < f.M; ++m) {
+      const float* zbm = zb + ((long)m * f.B + b) * 32;
+      f32x16 h0, acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) h0[r] = fmaxf(pre[r] + zbm[fc_row(r, h)], 0.f);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = b1r[r];
+      acc = M::mfma(w.w1p[0], fc_acc_frag<T>(h0, 0), acc);
+      acc = M::mfma(w.w1p[1], fc_acc_frag<T>(h0, 1), acc);
+      f32x16 h1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) h1[r] = fmaxf(acc[r], 0.f);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = b2r[r];
+      acc = M::mfma(w.w2p[0], fc_acc_frag<T>(h1, 0), acc);
+      acc = M::mfma(w.w2p[1], fc_acc_frag<T>(h1, 1), acc);
+      if (valid) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = fc_row(r, h);
+          if (co < f.Cout) f.out[(((long)b * f.M + m) * f.Cout + co) * HW + pix] = acc[r];
+        }
+      }
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void fcomb_bwd16_kernel(FcombBwdArgs a, const float* __restrict__ zb, float* __restrict__ dzb) {
+  typedef FCM<T> M;
+  extern __shared__ __attribute__((aligned(16))) unsigned char fc16_smem[];
+  uint16_t* tiles = reinterpret_cast<uint16_t*>(fc16_smem);        // 6 x [128][32]: dout | h1 | dh1 | h0 | dh0 | feat
+  constexpr int CHP = 128, TS = CHP * 32;                          // pixels per chunk (4 waves x 32), tile stride
+  const FcombArgs& f = a.f;
+  const long HW = (long)f.feat.H * f.feat.W;
+  const int b = blockIdx.y, tid = threadIdx.x, l = tid & 63, wave = tid >> 6, j = l & 31, h = l >> 5;
+  const uint16_t* fp = reinterpret_cast<const uint16_t*>(f.feat.p) + (f.bcast ? 0 : (long)b * HW * f.feat.ld);
+  const int WS = 32 + f.L;
+  FcW<T> w; fc_load_fwd_weights<T>(f, l, w);
+  // backward A fragments: W2^T (natural k = co), W1^T and W0f^T with the chained-K permutation
+  typename M::Frag w2t, w1tp[2], w0tp[2];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) M::set(w2t, e, (8 * h + e) < f.Cout ? f.w2[(8 * h + e) * 32 + j] : 0.f);
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      M::set(w1tp[s], e, f.w1[fc_perm(s, h, e) * 32 + j]);
+      M::set(w0tp[s], e, f.w0[fc_perm(s, h, e) * WS + j]);
+    }
+  float b1r[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) b1r[r] = f.b1[fc_row(r, h)];
+  typename M::Frag ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) M::set(ones, e, 1.f);
+
+  f32x16 aw[3], as1, as2, az;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { aw[0][r] = 0.f; aw[1][r] = 0.f; aw[2][r] = 0.f; as1[r] = 0.f; as2[r] = 0.f; }
+  // transposed-read lane roles
+  const int g = l >> 4, q = (l & 15) >> 2, p = l & 3;
+  const int nchunks = (int)((HW + CHP - 1) / CHP);
+  for (int ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+    // ---- per-wave: two 32-pixel column tiles; feat fragments and the shared pre-activation
+    f32x16 pre, dfe;
+    __syncthreads();                                       // previous chunk's transposed reads are done
+    const int lp = wave * 32 + j;                          // pixel inside the chunk
+    const long pix = (long)ch * CHP + lp;
+    const bool valid = pix < HW;
+    {
+      typename M::Frag fb[2];
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        union { V16 v; typename M::Frag fr; } x; x.v = zero16();
+        if (valid) x.v = *reinterpret_cast<const V16*>(fp + pix * f.feat.ld + 16 * s + 8 * h);
+        fb[s] = x.fr;
+        // feat tile: channels 16 s + 8 h .. +7 -> 16-byte chunk (2 s + h), swizzled
+        *reinterpret_cast<V16*>(tiles + 5 * TS + lp * 32 + (((2 * s + h) ^ ((lp >> 2) & 3)) * 8)) = x.v;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { pre[r] = 0.f; dfe[r] = 0.f; }
+      pre = M::mfma(w.w0n[0], fb[0], pre);
+      pre = M::mfma(w.w0n[1], fb[1], pre);
+    }
+    for (int m = 0; m < f.M; ++m) {
+      const float* zbm = zb + ((long)m * f.B + b) * 32;
+      if (m > 0) __syncthreads();                          // previous member's transposed reads are done
+      {
+        f32x16 h0, h1, acc, d1, d0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h0[r] = fmaxf(pre[r] + zbm[fc_row(r, h)], 0.f);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = b1r[r];
+        acc = M::mfma(w.w1p[0], fc_acc_frag<T>(h0, 0), acc);
+        acc = M::mfma(w.w1p[1], fc_acc_frag<T>(h0, 1), acc);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) h1[r] = fmaxf(acc[r], 0.f);
+        // dout fragment (natural k = co) and the dout tile (rows = co)
+        typename M::Frag fdo = fc_zero_frag<T>();
+        f32x16 dtile;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dtile[r] = 0.f;
+        if (valid) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e)
+            if (8 * h + e < f.Cout) M::set(fdo, e, a.dout[(((long)b * f.M + m) * f.Cout + 8 * h + e) * HW + pix]);
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (fc_row(r, h) < f.Cout) dtile[r] = a.dout[(((long)b * f.M + m) * f.Cout + fc_row(r, h)) * HW + pix];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        acc = M::mfma(w2t, fdo, acc);                      // W2^T . dout   (Cout <= 16 per k-step; Cout <= 32 handled below)
+        if (f.Cout > 16) {
+          typename M::Frag w2t2, fdo2 = fc_zero_frag<T>();
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            M::set(w2t2, e, (16 + 8 * h + e) < f.Cout ? f.w2[(16 + 8 * h + e) * 32 + j] : 0.f);
+            if (valid && 16 + 8 * h + e < f.Cout) M::set(fdo2, e, a.dout[(((long)b * f.M + m) * f.Cout + 16 + 8 * h + e) * HW + pix]);
+          }
+          acc = M::mfma(w2t2, fdo2, acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d1[r] = (h1[r] > 0.f && valid) ? acc[r] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        acc = M::mfma(w1tp[0], fc_acc_frag<T>(d1, 0), acc);
+        acc = M::mfma(w1tp[1], fc_acc_frag<T>(d1, 1), acc);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d0[r] = (h0[r] > 0.f && valid) ? acc[r] : 0.f;
+        dfe = M::mfma(w0tp[0], fc_acc_frag<T>(d0, 0), dfe);
+        dfe = M::mfma(w0tp[1], fc_acc_frag<T>(d0, 1), dfe);
+        fc_store_tile<T>(tiles + 0 * TS, lp, h, dtile);
+        fc_store_tile<T>(tiles + 1 * TS, lp, h, h1);
+        fc_store_tile<T>(tiles + 2 * TS, lp, h, d1);
+        fc_store_tile<T>(tiles + 3 * TS, lp, h, h0);
+        fc_store_tile<T>(tiles + 4 * TS, lp, h, d0);
+      }
+      __syncthreads();
+      // ---- weight-gradient products over the chunk's 256 pixels: wave owns k-steps wave, wave+4, ...
+#pragma unroll
+      for (int r = 0; r < 16; ++r) az[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < CHP / 64; ++ks) {
+        const int kk = wave + 4 * ks;
+        const int r0 = kk * 16 + 8 * h + q, r1 = r0 + 4;                      // pixel rows supplied by this lane
+        const int c0 = ((2 * (g & 1) + (p >> 1)) ^ ((r0 >> 2) & 3)) * 8 + 4 * (p & 1);
+        const int c1 = ((2 * (g & 1) + (p >> 1)) ^ ((r1 >> 2) & 3)) * 8 + 4 * (p & 1);
+        const int o0 = r0 * 32 + c0, o1 = r1 * 32 + c1;
+        typename M::Frag fl, fr;
+        fl = fc_tr_frag<typename M::Frag>(tiles + 0 * TS + o0, tiles + 0 * TS + o1);     // dout
+        fr = fc_tr_frag<typename M::Frag>(tiles + 1 * TS + o0, tiles + 1 * TS + o1);     // h1
+        aw[2] = M::mfma(fl, fr, aw[2]); as2 = M::mfma(fl, ones, as2);
+        fl = fc_tr_frag<typename M::Frag>(tiles + 2 * TS + o0, tiles + 2 * TS + o1);     // dh1
+        fr = fc_tr_frag<typename M::Frag>(tiles + 3 * TS + o0, tiles + 3 * TS + o1);     // h0
+        aw[1] = M::mfma(fl, fr, aw[1]); as1 = M::mfma(fl, ones, as1);
+        fl = fc_tr_frag<typename M::Frag>(tiles + 4 * TS + o0, tiles + 4 * TS + o1);     // dh0
+        fr = fc_tr_frag<typename M::Frag>(tiles + 5 * TS + o0, tiles + 5 * TS + o1);     // feat
+        aw[0] = M::mfma(fl, fr, aw[0]); az = M::mfma(fl, ones, az);
+      }
+      if (j == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) atomicAdd(dzb + ((long)m * f.B + b) * 32 + fc_row(r, h), az[r]);
+      }
+    }
+    if (a.dfeat.p) {
+      {
+        if (valid) {
+          T* dp = reinterpret_cast<T*>(a.dfeat.p) + ((long)b * HW + pix) * a.dfeat.ld;
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            float v[4] = {dfe[4 * g4], dfe[4 * g4 + 1], dfe[4 * g4 + 2], dfe[4 * g4 + 3]};
+            T* q4 = dp + 8 * g4 + 4 * h;
+            if (a.dfeat_accumulate) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] += ET<T>::ld(q4 + e);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) ET<T>::st(q4 + e, v[e]);
+          }
+        }
+      }
+    }
+  }
+  // ---- flush: D[row = o][col = c]; lane owns column j and rows fc_row(r, h)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int o = fc_row(r, h);
+    atomicAdd(a.dw0 + (long)o * WS + j, aw[0][r] * a.inv_scale);
+    atomicAdd(a.dw1 + (long)o * 32 + j, aw[1][r] * a.inv_scale);
+    if (o < f.Cout) atomicAdd(a.dw2 + (long)o * 32 + j, aw[2][r] * a.inv_scale);
+    if (j == 0) {
+      atomicAdd(a.db1 + o, as1[r] * a.inv_scale);
+      if (o < f.Cout) atomicAdd(a.db2 + o, as2[r] * a.inv_scale);
+    }
   }
 }
 
 // from dzb[m][b][o]: db0[o] += sum; dW0[o][F+l] += sum_{m,b} dzb z[m][b][l]; dz[m][b][l] = sum_o W0[o][F+l] dzb[m][b][o]
 __global__ void fcomb_bwd_z_kernel(const float* __restrict__ dzb, const float* __restrict__ z, const float* __restrict__ w0, int F, int L, int MB,
-                                   float* dz, float* dw0, float* db0) {
+                                   float* dz, float* dw0, float* db0, float inv_scale) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int WS = F + L;
   if (i < F * L) {
     const int o = i / L, l = i % L;
     float acc = 0.f;
     for (int mb = 0; mb < MB; ++mb) acc += dzb[(long)mb * F + o] * z[(long)mb * L + l];
-    dw0[(long)o * WS + F + l] += acc;
+    dw0[(long)o * WS + F + l] += acc * inv_scale;
   } else if (i < F * L + F) {
     const int o = i - F * L;
     float acc = 0.f;
     for (int mb = 0; mb < MB; ++mb) acc += dzb[(long)mb * F + o];
-    db0[o] += acc;
+    db0[o] += acc * inv_scale;
   }
   if (dz) {
     for (int j = i; j < MB * L; j += gridDim.x * blockDim.x) {
@@ -252,7 +578,12 @@ hipError_t launch_fcomb_fwd(const FcombArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(fcomb_zbias_kernel, dim3(cdiv((long)MB * a.F, 256)), dim3(256), 0, s, a.z, a.w0, a.b0, a.F, a.L, MB, zb);
   const long HW = (long)a.feat.H * a.feat.W;
   dim3 grid((unsigned)min((long)1024, (HW + 255) / 256), a.B);
-  if (a.F == 32) hipLaunchKernelGGL((fcomb_fwd_kernel<T, 32>), grid, dim3(256), 0, s, a, zb);
+  if (a.F == 32 && sizeof(T) == 2) {
+    if constexpr (sizeof(T) == 2) {
+      dim3 g16((unsigned)min((long)64, (HW + 127) / 128), a.B);
+      hipLaunchKernelGGL((fcomb_fwd16_kernel<T>), g16, dim3(256), 0, s, a, zb);
+    }
+  } else if (a.F == 32) hipLaunchKernelGGL((fcomb_fwd_kernel<T, 32>), grid, dim3(256), 0, s, a, zb);
   else if (a.F == 16) hipLaunchKernelGGL((fcomb_fwd_kernel<T, 16>), grid, dim3(256), 0, s, a, zb);
   else if (a.F == 8) hipLaunchKernelGGL((fcomb_fwd_kernel<T, 8>), grid, dim3(256), 0, s, a, zb);
   else return hipErrorInvalidValue;
@@ -278,11 +609,22 @@ hipError_t launch_fcomb_bwd(const FcombBwdArgs& a, hipStream_t s) {
     if (e != hipSuccess) return e;
     attr_done = true;
   }
-  if (f.F == 32) hipLaunchKernelGGL((fcomb_bwd_kernel<T, 32>), grid, dim3(256), lds, s, a, zb, dzb);
+  if (f.F == 32 && sizeof(T) == 2) {
+    if constexpr (sizeof(T) == 2) {
+      static bool attr16 = false;
+      if (!attr16) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(fcomb_bwd16_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 128 * 32 * 2);
+        if (e != hipSuccess) return e;
+        attr16 = true;
+      }
+      dim3 grid16((unsigned)min((long)24, (HW + 127) / 128), f.B);
+      hipLaunchKernelGGL((fcomb_bwd16_kernel<T>), grid16, dim3(256), 6 * 128 * 32 * 2, s, a, zb, dzb);
+    }
+  } else if (f.F == 32) hipLaunchKernelGGL((fcomb_bwd_kernel<T, 32>), grid, dim3(256), lds, s, a, zb, dzb);
   else if (f.F == 16) hipLaunchKernelGGL((fcomb_bwd_kernel<T, 16>), grid, dim3(256), lds, s, a, zb, dzb);
   else if (f.F == 8) hipLaunchKernelGGL((fcomb_bwd_kernel<T, 8>), grid, dim3(256), lds, s, a, zb, dzb);
   else return hipErrorInvalidValue;
-  hipLaunchKernelGGL(fcomb_bwd_z_kernel, dim3(cdiv((long)f.F * f.L + f.F, 256)), dim3(256), 0, s, dzb, f.z, f.w0, f.F, f.L, MB, a.dz, a.dw0, a.db0);
+  hipLaunchKernelGGL(fcomb_bwd_z_kernel, dim3(cdiv((long)f.F * f.L + f.F, 256)), dim3(256), 0, s, dzb, f.z, f.w0, f.F, f.L, MB, a.dz, a.dw0, a.db0, a.inv_scale);
   return hipGetLastError();
 }
 

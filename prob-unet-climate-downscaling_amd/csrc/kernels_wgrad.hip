@@ -1,0 +1,260 @@
+// 16-bit (f16 / bf16) convolution weight-gradient kernel for gfx950.
+//
+//   dw[co][ci][tap] = sum over (b, y, x) of dy[b,y,x,co] * in[b,y+dy-1,x+dx-1,ci]        (aten conv backward-weight)
+//
+// GEMM view: D[row = cout][col = cin] per tap, K = pixels.  Both MFMA operands need 8 consecutive K (= pixels) per lane
+// while the NHWC tiles in LDS are [pixel][channel]; the fragments are fetched with the gfx950 transposed LDS read
+// ds_read_b64_tr_b16 (lane i of a 16-lane group receives column i of a 4-row x 16-column block; probe-verified).
+//
+// Structure (one 256-thread block, 4 waves, one wave per SIMD):
+//   * block tile: 64 couts x BCI cins x all taps; K loop over the pixel tiles assigned to the block (split-K over the grid)
+//   * LDS tiles are stored as 32-channel sub-tiles [c/32][pixel][32] (64-byte rows): every transposed read of a 32-lane
+//     half touches all 64 banks exactly once (conflict-free), the 3x3 halo tile is shared by all 9 taps
+//   * double-buffered LDS + register prefetch: global loads of tile t+1 are issued before the MFMAs of tile t and written
+//     to the other LDS buffer afterwards; one barrier per tile
+//   * each block writes its fp32 partial tile to a slab [split][tap][cout][cin] with coalesced stores; a second kernel
+//     sums the slabs in a fixed order (bitwise reproducible, no float atomics) and adds into the fp32 gradient
+#include <cstdio>
+
+#include "pu_kernels.h"
+
+namespace pu {
+
+typedef short s16x4v __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4v* lds_s4_ptr;
+
+template <typename T> struct MMW;
+template <> struct MMW<f16> {
+  typedef f16x8 Frag;
+  __device__ static __forceinline__ f32x16 mfma(Frag a, Frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+template <> struct MMW<bf16> {
+  typedef bf16x8 Frag;
+  __device__ static __forceinline__ f32x16 mfma(Frag a, Frag b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+
+template <typename Frag>
+__device__ __forceinline__ Frag tr_frag(const uint16_t* p0, const uint16_t* p1) {
+  union { s16x4v h[2]; Frag f; } u;
+  u.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(p0));
+  u.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_ptr)(p1));
+  return u.f;
+}
+
+constexpr int WBCO = 64;
+
+template <typename T, int KS, int TH, int TW, int BCI>
+__global__ __launch_bounds__(256) void conv_wgrad16_kernel(WgradArgs a) {
+  typedef MMW<T> M;
+  constexpr int TAPS = KS * KS, PADP = KS / 2;
+  constexpr int BM = TH * TW;
+  constexpr int IH = TH + 2 * PADP, IW = TW + 2 * PADP, NPH = IH * IW;
+  constexpr int CIS = BCI / 32;                       // cin sub-tiles
+  constexpr int BUF = (2 * BM + CIS * NPH) * 32;      // elements per LDS buffer
+  constexpr int NVD = BM * 8 / 256;                   // 16-byte vectors of the dy tile per thread
+  constexpr int NVA_TOT = NPH * (BCI / 8);
+  constexpr int NVA = (NVA_TOT + 255) / 256;
+  // wave roles: BCI == 64: (cout sub-tile, cin sub-tile) x all taps;  BCI == 32: (cout sub-tile, tap half)
+  constexpr int NJ = BCI == 64 ? TAPS : (TAPS + 1) / 2;
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  uint16_t* lds = reinterpret_cast<uint16_t*>(smem_raw);
+
+  const int tid = threadIdx.x, l = tid & 63, wave = tid >> 6;
+  const int ct = wave & 1;
+  const int it = BCI == 64 ? (wave >> 1) : 0;
+  const int tap0 = BCI == 64 ? 0 : (wave >> 1) * NJ;
+  const int co0 = blockIdx.y * WBCO, ci0 = blockIdx.z * BCI;
+  const int tiles_x = a.W / TW, tiles_y = a.H / TH;
+  const int ntiles = tiles_x * tiles_y * a.B;
+  const uint16_t* dy = reinterpret_cast<const uint16_t*>(a.dy);
+  const uint16_t* in = reinterpret_cast<const uint16_t*>(a.in);
+
+  f32x16 acc[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  V16 rd[NVD], ra[NVA];
+  auto gload = [&](int tile) {
+    int pt = tile;
+    const int tx0 = (pt % tiles_x) * TW; pt /= tiles_x;
+    const int ty0 = (pt % tiles_y) * TH; pt /= tiles_y;
+    const int b = pt;
+#pragma unroll
+    for (int k = 0; k < NVD; ++k) {
+      const int i = tid + k * 256;
+      const int pix = i >> 3, cv = i & 7;
+      const int gy = ty0 + pix / TW, gx = tx0 + pix % TW;
+      const int co = co0 + cv * 8;
+      rd[k] = zero16();
+      if (co < a.Cout) rd[k] = *reinterpret_cast<const V16*>(dy + ((size_t)(b * a.H + gy) * a.W + gx) * a.dy_ld + co);
+    }
+#pragma unroll
+    for (int k = 0; k < NVA; ++k) {
+      const int i = tid + k * 256;
+      ra[k] = zero16();
+      if (i < NVA_TOT) {
+        const int hp = i / (BCI / 8), cv = i % (BCI / 8);
+        const int gy = ty0 + hp / IW - PADP, gx = tx0 + hp % IW - PADP;
+        const int ci = ci0 + cv * 8;
+        if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && ci < a.Cin)
+          ra[k] = *reinterpret_cast<const V16*>(in + ((size_t)(b * a.H + gy) * a.W + gx) * a.in_ld + ci);
+      }
+    }
+  };
+  auto lstore = [&](int buf) {
+    uint16_t* sDy = lds + buf * BUF;
+    uint16_t* sA = sDy + 2 * BM * 32;
+#pragma unroll
+    for (int k = 0; k < NVD; ++k) {
+      const int i = tid + k * 256;
+      const int pix = i >> 3, cv = i & 7;
+      *reinterpret_cast<V16*>(sDy + ((cv >> 2) * BM + pix) * 32 + (cv & 3) * 8) = rd[k];
+    }
+#pragma unroll
+    for (int k = 0; k < NVA; ++k) {
+      const int i = tid + k * 256;
+      if (i < NVA_TOT) {
+        const int hp = i / (BCI / 8), cv = i % (BCI / 8);
+        *reinterpret_cast<V16*>(sA + ((cv >> 2) * NPH + hp) * 32 + (cv & 3) * 8) = ra[k];
+      }
+    }
+  };
+
+  // lane roles of the transposed reads
+  const int g = l >> 4, h = l >> 5, q = (l & 15) >> 2, p = l & 3;
+  const int cb = 16 * (g & 1) + 4 * p;
+
+  int tile = blockIdx.x;
+  int cur = 0;
+  if (tile < ntiles) { gload(tile); lstore(0); }
+  __syncthreads();
+  for (; tile < ntiles; tile += gridDim.x) {
+    const int nxt = tile + gridDim.x;
+    if (nxt < ntiles) gload(nxt);
+    const uint16_t* sDy = lds + cur * BUF + (ct * BM) * 32 + cb;
+    const uint16_t* sA = lds + cur * BUF + 2 * BM * 32 + (it * NPH) * 32 + cb;
+#pragma unroll 2
+    for (int kk = 0; kk < BM / 16; ++kk) {
+      const int m0 = kk * 16 + 8 * h + q, m1 = m0 + 4;
+      const typename M::Frag fa = tr_frag<typename M::Frag>(sDy + m0 * 32, sDy + m1 * 32);
+      const int h0 = ((m0 / TW) * IW + (m0 % TW)) * 32, h1 = ((m1 / TW) * IW + (m1 % TW)) * 32;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int t = tap0 + j;
+        if (t < TAPS) {
+          const int toff = ((t / KS) * IW + (t % KS)) * 32;
+          const typename M::Frag fb = tr_frag<typename M::Frag>(sA + h0 + toff, sA + h1 + toff);
+          acc[j] = M::mfma(fa, fb, acc[j]);
+        }
+      }
+    }
+    if (nxt < ntiles) lstore(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- partial tile -> slab [split][tap][cout_pad][cin_pad] (cin contiguous: 128-byte coalesced rows)
+  const int cout_pad = gridDim.y * WBCO, cin_pad = gridDim.z * BCI;
+  float* slab = a.slab + (size_t)blockIdx.x * TAPS * cout_pad * cin_pad;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int t = tap0 + j;
+    if (t < TAPS) {
+      const int ci = ci0 + it * 32 + (l & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        slab[((size_t)t * cout_pad + co) * cin_pad + ci] = acc[j][r];
+      }
+    }
+  }
+}
+
+// dw[co][ci][tap] += inv_scale * sum_s slab[s][tap][co][ci]   (fixed order -> reproducible)
+// block = 64 consecutive elements x 4 split lanes (coalesced 256-byte rows per split), LDS combine
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int split, int taps, int cout_pad, int cin_pad, int Cout, int Cin,
+                                                            float* __restrict__ dw, float inv_scale) {
+  __shared__ float red[4][64];
+  const long total = (long)taps * Cout * Cin;
+  const long i = (long)blockIdx.x * 64 + (threadIdx.x & 63);
+  const int lane = threadIdx.x >> 6;
+  float s = 0.f;
+  int ci = 0, co = 0, t = 0;
+  if (i < total) {
+    ci = (int)(i % Cin); co = (int)((i / Cin) % Cout); t = (int)(i / ((long)Cin * Cout));
+    const size_t off = ((size_t)t * cout_pad + co) * cin_pad + ci;
+    const size_t stride = (size_t)taps * cout_pad * cin_pad;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int k = lane;
+    for (; k + 12 < split; k += 16) {
+      s0 += slab[off + (size_t)k * stride]; s1 += slab[off + (size_t)(k + 4) * stride];
+      s2 += slab[off + (size_t)(k + 8) * stride]; s3 += slab[off + (size_t)(k + 12) * stride];
+    }
+    for (; k < split; k += 4) s0 += slab[off + (size_t)k * stride];
+    s = (s0 + s1) + (s2 + s3);
+  }
+  red[lane][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (lane == 0 && i < total) {
+    const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    dw[((size_t)co * Cin + ci) * taps + t] += v * inv_scale;
+  }
+}
+
+template <typename T, int KS, int TH, int TW, int BCI>
+static hipError_t launch_wg16(const WgradArgs& a, hipStream_t s) {
+  constexpr int PADP = KS / 2, BM = TH * TW, NPH = (TH + 2 * PADP) * (TW + 2 * PADP), TAPS = KS * KS;
+  constexpr size_t lds = (size_t)2 * (2 * BM + (BCI / 32) * NPH) * 32 * 2;
+  auto kern = conv_wgrad16_kernel<T, KS, TH, TW, BCI>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  const int ntiles = (a.W / TW) * (a.H / TH) * a.B;
+  const int gy = cdiv(a.Cout, WBCO), gz = cdiv(a.Cin, BCI);
+  const long per_split = (long)TAPS * gy * WBCO * gz * BCI;
+  int split = cdiv(768, gy * gz);                        // ~3 blocks per CU over the chip
+  if (split > ntiles) split = ntiles;
+  if ((long)split * per_split > a.slab_floats) split = (int)(a.slab_floats / per_split);
+  if (split < 1) return hipErrorInvalidValue;
+  WgradArgs b = a;
+  char tag[128];
+  const bool prof = prof_enabled();
+  if (prof) {
+    snprintf(tag, sizeof tag, "conv_wgrad16_kernel<%s,%d,%d,%d,%d>", ET<T>::DT == 1 ? "f16" : "bf16", KS, TH, TW, BCI);
+    const double px = (double)a.B * a.H * a.W;
+    prof_record(tag, 2.0 * px * a.Cout * (double)a.Cin * a.taps, px * (a.Cin + a.Cout) * 2 + (double)a.Cout * a.Cin * a.taps * 4, s, true);
+  }
+  hipLaunchKernelGGL(kern, dim3(split, gy, gz), dim3(256), lds, s, b);
+  if (prof) prof_record(tag, 0, 0, s, false);
+  const long total = (long)TAPS * a.Cout * a.Cin;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, a.slab, split, TAPS,
+                     gy * WBCO, gz * BCI, a.Cout, a.Cin, a.dw, a.inv_scale);
+  return hipGetLastError();
+}
+
+template <typename T, int KS>
+static hipError_t launch_wg16_ks(const WgradArgs& a, hipStream_t s) {
+  const bool wide = a.Cin > 32;
+  if (a.W % 32 == 0 && a.H % 4 == 0) return wide ? launch_wg16<T, KS, 4, 32, 64>(a, s) : launch_wg16<T, KS, 4, 32, 32>(a, s);
+  if (a.W % 16 == 0 && a.H % 8 == 0) return wide ? launch_wg16<T, KS, 8, 16, 64>(a, s) : launch_wg16<T, KS, 8, 16, 32>(a, s);
+  if (a.W % 8 == 0 && a.H % 8 == 0) return wide ? launch_wg16<T, KS, 8, 8, 64>(a, s) : launch_wg16<T, KS, 8, 8, 32>(a, s);
+  return hipErrorInvalidValue;
+}
+
+template <typename T>
+hipError_t launch_wgrad16(const WgradArgs& a, hipStream_t s) {
+  if (!a.slab) return hipErrorInvalidValue;
+  if (a.taps == 9) return launch_wg16_ks<T, 3>(a, s);
+  if (a.taps == 1) return launch_wg16_ks<T, 1>(a, s);
+  return hipErrorInvalidValue;
+}
+template hipError_t launch_wgrad16<f16>(const WgradArgs&, hipStream_t);
+template hipError_t launch_wgrad16<bf16>(const WgradArgs&, hipStream_t);
+
+}  // namespace pu

@@ -17,13 +17,16 @@ struct ConvArgs {
 struct WgradArgs {
   const void* dy; int dy_ld; int Cout;
   const void* in; int in_ld; int Cin;
-  float* dw;                                     // fp32 [Cout][Cin][ks][ks], atomically accumulated
+  float* dw;                                     // fp32 [Cout][Cin][ks][ks], ADDED into
   int B, H, W; int taps;
+  float* slab; long slab_floats;                 // split-K partial slabs (16-bit path; required there)
+  float inv_scale;                               // parameter gradients are multiplied by this (loss-scale removal)
 };
 struct PackDesc { long src_off; long dst_off; int Cout, Cin, taps, rows_pk, k_pk, mode; };
 
 template <typename T> hipError_t launch_conv(const ConvArgs&, hipStream_t);
 template <typename T> hipError_t launch_wgrad(const WgradArgs&, hipStream_t);
+template <typename T> hipError_t launch_wgrad16(const WgradArgs&, hipStream_t);   // kernels_wgrad.hip (f16 / bf16)
 template <typename T> hipError_t launch_pack(const float* params, void* packed, const PackDesc* descs_dev, int ndesc, hipStream_t);
 
 // ---------------------------------------------------------------- layout / elementwise
@@ -56,6 +59,7 @@ struct GNBwdArgs {
   TV dx; int accumulate;      // grad wrt x
   float* dgamma; float* dbeta; float* dscale; float* dshift;   // fp32 [C], ADDED into (nullable scale/shift)
   float* part2;               // [B][nchunk][C][2]
+  float inv_scale;            // parameter gradients are multiplied by this
   float* coef2;               // [B][C][3] (P, Q, R)
 };
 template <typename T> hipError_t launch_gn_bwd(const GNBwdArgs&, hipStream_t);
@@ -67,7 +71,7 @@ template <typename T> hipError_t launch_maxpool(TV x, TV y, hipStream_t);
 template <typename T> hipError_t launch_maxpool_bwd(TV x, TV dy, TV dx, hipStream_t);                      // dx written
 template <typename T> hipError_t launch_relu_bwd(TV y, TV dy, hipStream_t);                                // dy *= (y>0), in place
 // dbias[c] += sum over pixels of dy[..., c]; part: fp32 [nchunk][C]
-template <typename T> hipError_t launch_bias_grad(TV dy, float* dbias0, float* dbias1_or_null, float* part, int nchunk, hipStream_t);
+template <typename T> hipError_t launch_bias_grad(TV dy, float* dbias0, float* dbias1_or_null, float* part, int nchunk, float inv_scale, hipStream_t);
 
 // ---------------------------------------------------------------- Gaussian-encoder heads / latent / losses
 // h[b,c] = mean over pixels; mu = Wmu h + bmu; ls = Wls h + bls.  hbuf fp32 [B][C]
@@ -75,7 +79,7 @@ template <typename T> hipError_t launch_heads_fwd(TV x, const float* wmu, const 
                                                   int L, float* hbuf, float* mu, float* ls, hipStream_t);
 template <typename T> hipError_t launch_heads_bwd(TV x_shape, TV dx, const float* hbuf, const float* wmu, const float* wls,
                                                   const float* dmu, const float* dls, int L,
-                                                  float* dwmu, float* dbmu, float* dwls, float* dbls, hipStream_t);
+                                                  float* dwmu, float* dbmu, float* dwls, float* dbls, float inv_scale, hipStream_t);
 struct LatentArgs {
   const float* mu_q; const float* ls_q; const float* mu_p; const float* ls_p;   // [B,L]
   const float* eps;            // [M,B,L]
@@ -115,6 +119,7 @@ struct FcombBwdArgs {
   TV dfeat; int dfeat_accumulate;   // NHWC T grad wrt feat (nullable p)
   float* dz;                   // [M,B,L] written (must be zeroed by caller) or null
   float* dw0; float* db0; float* dw1; float* db1; float* dw2; float* db2;   // ADDED (atomics)
+  float inv_scale;             // parameter gradients are multiplied by this (dz / dfeat keep the loss scale)
 };
 template <typename T> hipError_t launch_fcomb_bwd(const FcombBwdArgs&, hipStream_t);
 

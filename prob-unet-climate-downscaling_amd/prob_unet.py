@@ -327,6 +327,7 @@ class ProbabilisticUNet(nn.Module):
         cfg.H, cfg.W, cfg.max_batch, cfg.max_members = H, W, max_batch, max_members
         cfg.dtype = L.DTYPES[self.compute_dtype]
         cfg.dropout_p = self.dropout
+        cfg.grad_scale = float(getattr(self, "grad_scale", 0.0))
         return cfg
 
     def _query_table(self):

@@ -212,3 +212,26 @@ def test_cfg1_elbo_against_oracle_with_dropout_off():
         cos = float((gr[k].double().flatten() @ v.double().flatten()) / (gr[k].double().norm() * v.double().norm()))
         assert rel < 3e-2 and cos > 0.9995, (k, rel, cos)
     assert float(np.median(rels)) < 2e-3, float(np.median(rels))
+
+
+def test_f16_static_loss_scale_keeps_tiny_gradients():
+    """With beta_0 = 1e-4 the activation gradients (~1e-8) would flush to zero in fp16; the engine's automatic static
+    loss scale (pu_config.grad_scale = 0) keeps them and removes the scale from every parameter gradient."""
+    meta, g = load_golden("mid11")
+    cfg = oracle_cfg(meta["config"]); P = filled_params(cfg)
+    m = build(meta, dtype="f16").train(); m.dropout = 0.0
+    m.beta_0, m.beta_1 = 1e-4, 0.0
+    x, y, eps = t(g["x"]).to(DEV), t(g["y"]).to(DEV), t(g["eps"]).to(DEV)
+    total, recon, kl = m.elbo(x, y, None, M=eps.shape[0], eps=eps)
+    total.backward()
+    r, og = O.elbo_with_grads(P, cfg, t(g["x"]), t(g["y"]), t(g["eps"]), beta0=1e-4, beta1=0.0)
+    gr = grads_of(m)
+    num = den1 = den2 = 0.0
+    for k, v in og.items():
+        if k.startswith("unet.") or k.startswith("fcomb."):
+            a = gr[k].double().flatten(); b = v.double().flatten()
+            num += float(a @ b); den1 += float(a @ a); den2 += float(b @ b)
+    assert den1 > 0.25 * den2, (den1, den2)                    # not flushed to zero
+    # the closed-form filler network amplifies rounding ~1e4x (torch fp32 vs fp64: 2e-3), so fp16 U-Net gradients agree
+    # with the fp32 oracle only to a cosine of ~0.985 with or without the loss scale
+    assert num / (den1 ** 0.5 * den2 ** 0.5) > 0.97
