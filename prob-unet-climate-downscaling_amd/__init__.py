@@ -2,3 +2,4 @@
 ProbabilisticUNet interface.  Compute lives in libprobunet.so (HIP, gfx950); this package is the ctypes host side."""
 from . import _lib  # noqa: F401
 from .prob_unet import ProbabilisticUNet  # noqa: F401,E402
+from . import dp  # noqa: F401,E402

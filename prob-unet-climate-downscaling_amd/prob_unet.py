@@ -278,6 +278,7 @@ class ProbabilisticUNet(nn.Module):
         self._last_mu = {}
         self._dp_group = None
         self._dp_world = 1
+        self.dp_bucket_elems = 0
 
         # ---- parameter tree from the engine's own table (names/shapes/order of the reference state_dict)
         table = self._query_table()
@@ -414,9 +415,8 @@ class ProbabilisticUNet(nn.Module):
         Under data parallelism the engine gradients are first averaged over the process group (RCCL all-reduce)."""
         eg = self._engine_grads[lo:hi]
         if self._dp_world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(eg, op=dist.ReduceOp.SUM, group=self._dp_group)
-            eg.mul_(1.0 / self._dp_world)
+            from .dp import allreduce_mean_
+            allreduce_mean_(eg, self._dp_group, self.dp_bucket_elems)
         if g is not None:
             eg = eg * g.reshape(())
         P = self._params_in(lo, hi)
