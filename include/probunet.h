@@ -137,6 +137,9 @@ int pu_profile_collect(pu_prof_entry* out, int max_entries);
  * All pointers device fp32. Syncs the stream. */
 int pu_op_conv(int dtype, int mode, int ks, int relu, int B, int Cin, int Cout, int H, int W,
                const float* x, const float* w, const float* bias, const float* dy, float* out, void* stream);
+/* Micro-benchmark: average microseconds (HIP events, `iters` back-to-back launches) of one convolution kernel launch on
+ * NHWC data already in HBM. mode 0 forward, 1 data gradient, 2 weight gradient (incl. its slab reduce). Syncs. */
+int pu_bench_conv(int dtype, int mode, int ks, int B, int Cin, int Cout, int H, int W, int iters, float* out_us, void* stream);
 /* GroupNorm(+scale/shift)+SiLU(+dropout drop_p with the counter-hash mask of drop_seed; resample 0 only) with optional
  * 2x resample (0 none, 1 avg-pool down, 2 nearest up), forward and backward, on NCHW fp32 tensors. Syncs. */
 int pu_op_gnsilu(int dtype, int resample, int B, int C, int H, int W, const float* x, const float* gamma,

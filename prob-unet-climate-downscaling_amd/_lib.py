@@ -74,6 +74,8 @@ def lib():
     L.pu_profile_collect.restype = i32; L.pu_profile_collect.argtypes = [C.POINTER(PuProfEntry), i32]
     L.pu_op_conv.restype = i32
     L.pu_op_conv.argtypes = [i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]
+    L.pu_bench_conv.restype = i32
+    L.pu_bench_conv.argtypes = [i32, i32, i32, i32, i32, i32, i32, i32, i32, C.POINTER(C.c_float), vp]
     L.pu_op_gnsilu.restype = i32
     L.pu_op_gnsilu.argtypes = [i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, u64, vp]
     _lib = L

@@ -24,6 +24,7 @@ struct ConvL {
   int cin_pk = 0, rows_fwd = 0;        // forward pack: [rows_fwd][taps][cin_pk]
   int cout_pk = 0, rows_bwd = 0;       // dgrad pack:   [rows_bwd][taps][cout_pk]
   bool need_dgrad = true;
+  bool frag = false;                   // packed weights are fragment-major (conv3 kernel)
 };
 struct GNL {
   int C = 0, G = 0, nchunk = 1;
@@ -137,17 +138,18 @@ static int64_t add_param(pu_ctx* c, const std::string& name, std::initializer_li
   return d.offset;
 }
 
-static void setup_conv(pu_ctx* c, ConvL& L, int cin, int cout, int ks, int64_t w_off, int64_t b_off, bool need_dgrad) {
+static void setup_conv(pu_ctx* c, ConvL& L, int cin, int cout, int ks, int64_t w_off, int64_t b_off, bool need_dgrad, int rh, int rw) {
   L.cin = cin; L.cout = cout; L.ks = ks; L.w_off = w_off; L.b_off = b_off; L.need_dgrad = need_dgrad;
+  L.frag = conv_uses_frag_layout((int)c->esz, rh, rw);
   const int taps = ks * ks;
   L.cin_pk = rup(cin, 32); L.rows_fwd = rup(cout, 32);
   L.pk_fwd = c->packed_elems; c->packed_elems += (long)L.rows_fwd * taps * L.cin_pk;
-  PackDesc d; d.src_off = w_off; d.dst_off = L.pk_fwd; d.Cout = cout; d.Cin = cin; d.taps = taps; d.rows_pk = L.rows_fwd; d.k_pk = L.cin_pk; d.mode = 0;
+  PackDesc d; d.src_off = w_off; d.dst_off = L.pk_fwd; d.Cout = cout; d.Cin = cin; d.taps = taps; d.rows_pk = L.rows_fwd; d.k_pk = L.cin_pk; d.mode = L.frag ? 2 : 0;
   c->descs.push_back(d);
   if (need_dgrad) {
     L.cout_pk = rup(cout, 32); L.rows_bwd = rup(cin, 32);
     L.pk_bwd = c->packed_elems; c->packed_elems += (long)L.rows_bwd * taps * L.cout_pk;
-    d.dst_off = L.pk_bwd; d.rows_pk = L.rows_bwd; d.k_pk = L.cout_pk; d.mode = 1;
+    d.dst_off = L.pk_bwd; d.rows_pk = L.rows_bwd; d.k_pk = L.cout_pk; d.mode = L.frag ? 3 : 1;
     c->descs.push_back(d);
   }
 }
@@ -231,7 +233,7 @@ static int build_plan(pu_ctx* c) {
     if (!s.is_block) {
       const int64_t w = add_param(c, p + ".weight", {s.cout, s.cin, 3, 3});
       const int64_t bb = add_param(c, p + ".bias", {s.cout});
-      setup_conv(c, b.conv0, s.cin, s.cout, 3, w, bb, false);
+      setup_conv(c, b.conv0, s.cin, s.cout, 3, w, bb, false, oH, oW);
       return;
     }
     const int64_t g0 = add_param(c, p + ".norm0.weight", {s.cin});
@@ -250,13 +252,13 @@ static int build_plan(pu_ctx* c) {
       const int64_t ws = add_param(c, p + ".skip.weight", {s.cout, s.cin, 1, 1});
       const int64_t bs = add_param(c, p + ".skip.bias", {s.cout});
       if (s.up || s.down) add_param(c, p + ".skip.resample_filter", {1, 1, 2, 2}, true);
-      setup_conv(c, b.skipc, s.cin, s.cout, 1, ws, bs, true);
+      setup_conv(c, b.skipc, s.cin, s.cout, 1, ws, bs, true, oH, oW);
     } else if (b.skip == SK_RESAMPLE) add_param(c, p + ".skip.resample_filter", {1, 1, 2, 2}, true);
     const int rs = s.down ? RS_DOWN : (s.up ? RS_UP : RS_NONE);
     setup_gn(c, b.n0, s.cin, (long)inH * inW, g0, b0, -1, rs, false, 0);
-    setup_conv(c, b.conv0, s.cin, s.cout, 3, w0, bb0, true);
+    setup_conv(c, b.conv0, s.cin, s.cout, 3, w0, bb0, true, oH, oW);
     setup_gn(c, b.n1, s.cout, (long)oH * oW, g1, b1, ab, RS_NONE, true, drop_stream++);
-    setup_conv(c, b.conv1, s.cout, s.cout, 3, w1, bb1, true);
+    setup_conv(c, b.conv1, s.cout, s.cout, 3, w1, bb1, true, oH, oW);
     b.a0 = alloc_act(c, mb, oH, oW, s.cin);
     b.c0 = alloc_act(c, mb, oH, oW, s.cout);
     b.h1 = alloc_act(c, mb, oH, oW, s.cout);
@@ -289,7 +291,7 @@ static int build_plan(pu_ctx* c) {
     const int64_t ow = add_param(c, "unet.out_conv.weight", {cf.num_filters[0], c_last, 3, 3});
     const int64_t obb = add_param(c, "unet.out_conv.bias", {cf.num_filters[0]});
     setup_gn(c, c->out_norm, c_last, (long)H * W, og, ob, -1, RS_NONE, false, 0);
-    setup_conv(c, c->out_conv, c_last, cf.num_filters[0], 3, ow, obb, true);
+    setup_conv(c, c->out_conv, c_last, cf.num_filters[0], 3, ow, obb, true, H, W);
     c->out_a = alloc_act(c, mb, H, W, c_last);
     c->feat = alloc_act(c, mb, H, W, cf.num_filters[0]);
   }
@@ -308,7 +310,7 @@ static int build_plan(pu_ctx* c) {
         const int co = cf.num_filters[lv];
         const int64_t w = add_param(c, std::string(net) + ".encoder." + std::to_string(idx) + ".weight", {co, cin, 3, 3});
         const int64_t b = add_param(c, std::string(net) + ".encoder." + std::to_string(idx) + ".bias", {co});
-        ConvL L; setup_conv(c, L, cin, co, 3, w, b, !(lv == 0 && k == 0));
+        ConvL L; setup_conv(c, L, cin, co, 3, w, b, !(lv == 0 && k == 0), curH, curW);
         g.convs.push_back(L);
         if (!(pooled && k == 0)) g.ins.push_back(cur);
         g.pool_before.push_back(pooled && k == 0 ? 1 : 0);
@@ -389,7 +391,7 @@ static int conv_fwd(pu_ctx* c, const ConvL& L, TV in, TV out, int B, bool relu, 
   a.bias = P(c, L.b_off);
   a.res = res ? res->p : nullptr; a.res_ld = res ? res->ld : 0;
   a.out = out.p; a.out_ld = out.ld; a.Cout = L.cout;
-  a.B = B; a.H = out.H; a.W = out.W; a.relu = relu ? 1 : 0; a.accumulate = accumulate;
+  a.B = B; a.H = out.H; a.W = out.W; a.relu = relu ? 1 : 0; a.accumulate = accumulate; a.frag_layout = L.frag ? 1 : 0;
   if (a.Cin > L.cin_pk) a.Cin = L.cin_pk;
   CKH(launch_conv<T>(a, s));
   return PU_OK;
@@ -404,7 +406,7 @@ static int conv_dgrad(pu_ctx* c, const ConvL& L, TV dy, TV dx, int B, int accumu
   a.out = dx.p; a.out_ld = dx.ld;
   a.Cout = dx.C;                      // write every allocated plane (planes >= L.cin receive zeros from zero-padded weights)
   if (a.Cout > L.rows_bwd) a.Cout = L.rows_bwd;
-  a.B = B; a.H = dx.H; a.W = dx.W; a.relu = 0; a.accumulate = accumulate;
+  a.B = B; a.H = dx.H; a.W = dx.W; a.relu = 0; a.accumulate = accumulate; a.frag_layout = L.frag ? 1 : 0;
   CKH(launch_conv<T>(a, s));
   return PU_OK;
 }
@@ -898,26 +900,26 @@ static int op_conv_t(int mode, int ks, int relu, int B, int Cin, int Cout, int H
   tx.p = xin; tx.B = B; tx.H = H; tx.W = W; tx.C = cin_a; tx.ld = cin_a;
   ty.p = yb; ty.B = B; ty.H = H; ty.W = W; ty.C = cout_a; ty.ld = cout_a;
   if (mode == 0) {
-    d.rows_pk = rup(Cout, 32); d.k_pk = rup(Cin, 32); d.mode = 0;
+    d.rows_pk = rup(Cout, 32); d.k_pk = rup(Cin, 32); d.mode = conv_uses_frag_layout((int)esz, H, W) ? 2 : 0;
     CK0(hipMalloc(&wp, (size_t)d.rows_pk * taps * d.k_pk * esz));
     CK0(hipMemcpyAsync(dd, &d, sizeof d, hipMemcpyHostToDevice, s));
     CK0(launch_pack<T>(w, wp, dd, 1, s));
     CK0(launch_nchw_to_nhwc<T>(x, (long)Cin * H * W, Cin, nullptr, 0, tx, s));
     ConvArgs a; memset(&a, 0, sizeof a);
     a.in = xin; a.in_ld = cin_a; a.Cin = cin_a; a.wpk = wp; a.cin_pk = d.k_pk; a.cout_pk = d.rows_pk; a.taps = taps; a.bias = bias;
-    a.out = yb; a.out_ld = cout_a; a.Cout = Cout; a.B = B; a.H = H; a.W = W; a.relu = relu;
+    a.out = yb; a.out_ld = cout_a; a.Cout = Cout; a.B = B; a.H = H; a.W = W; a.relu = relu; a.frag_layout = d.mode >= 2;
     CK0(hipMemsetAsync(yb, 0, npix * cout_a * esz, s));
     CK0(launch_conv<T>(a, s));
     CK0(launch_nhwc_to_nchw<T>(ty, Cout, out, 0, s));
   } else if (mode == 1) {
-    d.rows_pk = rup(Cin, 32); d.k_pk = rup(Cout, 32); d.mode = 1;
+    d.rows_pk = rup(Cin, 32); d.k_pk = rup(Cout, 32); d.mode = conv_uses_frag_layout((int)esz, H, W) ? 3 : 1;
     CK0(hipMalloc(&wp, (size_t)d.rows_pk * taps * d.k_pk * esz));
     CK0(hipMemcpyAsync(dd, &d, sizeof d, hipMemcpyHostToDevice, s));
     CK0(launch_pack<T>(w, wp, dd, 1, s));
     CK0(launch_nchw_to_nhwc<T>(dy, (long)Cout * H * W, Cout, nullptr, 0, ty, s));
     ConvArgs a; memset(&a, 0, sizeof a);
     a.in = yb; a.in_ld = cout_a; a.Cin = cout_a; a.wpk = wp; a.cin_pk = d.k_pk; a.cout_pk = d.rows_pk; a.taps = taps;
-    a.out = xin; a.out_ld = cin_a; a.Cout = cin_a; a.B = B; a.H = H; a.W = W;
+    a.out = xin; a.out_ld = cin_a; a.Cout = cin_a; a.B = B; a.H = H; a.W = W; a.frag_layout = d.mode >= 2;
     CK0(launch_conv<T>(a, s));
     CK0(launch_nhwc_to_nchw<T>(tx, Cin, out, 0, s));
   } else {
@@ -984,6 +986,58 @@ static int op_gn_t(int resample, int B, int C, int H, int W, const float* x, con
 done:
   (void)hipFree(xb); (void)hipFree(yb); (void)hipFree(dyb); (void)hipFree(dxb); (void)hipFree(dvb); (void)hipFree(ws);
   return rc;
+}
+
+// micro-benchmark of one convolution launch on random NHWC data (no layout conversion in the timed region)
+template <typename T>
+static int bench_conv_t(int mode, int ks, int B, int Cin, int Cout, int H, int W, int iters, float* out_us, hipStream_t s) {
+  int rc = PU_OK;
+  const size_t esz = sizeof(T); const int taps = ks * ks;
+  const long npix = (long)B * H * W;
+  T *xin = nullptr, *yb = nullptr, *wp = nullptr; float *wf = nullptr, *slab = nullptr, *dw = nullptr; PackDesc* dd = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr; float ms = 0.f;
+  PackDesc d; d.src_off = 0; d.dst_off = 0; d.Cout = Cout; d.Cin = Cin; d.taps = taps;
+  const long nw = (long)Cout * Cin * taps;
+  CK0(hipMalloc(&xin, npix * Cin * esz)); CK0(hipMalloc(&yb, npix * Cout * esz)); CK0(hipMalloc(&wf, nw * 4)); CK0(hipMalloc(&dw, nw * 4));
+  CK0(hipMalloc(&dd, sizeof(PackDesc))); CK0(hipMalloc(&slab, 32L * 1024 * 1024 * 4));
+  CK0(launch_fill(wf, 0.01f, nw, s));
+  CK0(hipMemsetAsync(xin, 0x3c, npix * Cin * esz, s)); CK0(hipMemsetAsync(yb, 0x3c, npix * Cout * esz, s));   // ~1.0 in f16 / small in bf16
+  CK0(hipEventCreate(&e0)); CK0(hipEventCreate(&e1));
+  if (mode == 0 || mode == 1) {
+    const int ci = mode == 0 ? Cin : Cout, co = mode == 0 ? Cout : Cin;
+    d.Cout = co; d.Cin = ci; d.rows_pk = rup(co, 32); d.k_pk = rup(ci, 32); d.mode = conv_uses_frag_layout((int)esz, H, W) ? 2 : 0;
+    CK0(hipMalloc(&wp, (size_t)d.rows_pk * taps * d.k_pk * esz));
+    CK0(hipMemcpyAsync(dd, &d, sizeof d, hipMemcpyHostToDevice, s));
+    CK0(launch_pack<T>(wf, wp, dd, 1, s));
+    ConvArgs a; memset(&a, 0, sizeof a);
+    a.in = mode == 0 ? (void*)xin : (void*)yb; a.in_ld = ci; a.Cin = ci; a.wpk = wp; a.cin_pk = d.k_pk; a.cout_pk = d.rows_pk; a.taps = taps;
+    a.out = mode == 0 ? (void*)yb : (void*)xin; a.out_ld = co; a.Cout = co; a.B = B; a.H = H; a.W = W; a.frag_layout = d.mode >= 2;
+    for (int i = 0; i < 3; ++i) CK0(launch_conv<T>(a, s));
+    CK0(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i) CK0(launch_conv<T>(a, s));
+    CK0(hipEventRecord(e1, s));
+  } else {
+    WgradArgs a; memset(&a, 0, sizeof a);
+    a.dy = yb; a.dy_ld = Cout; a.Cout = Cout; a.in = xin; a.in_ld = Cin; a.Cin = Cin; a.dw = dw; a.B = B; a.H = H; a.W = W; a.taps = taps;
+    a.slab = slab; a.slab_floats = 32L * 1024 * 1024; a.inv_scale = 1.f;
+    for (int i = 0; i < 3; ++i) CK0(launch_wgrad<T>(a, s));
+    CK0(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i) CK0(launch_wgrad<T>(a, s));
+    CK0(hipEventRecord(e1, s));
+  }
+  CK0(hipEventSynchronize(e1)); CK0(hipEventElapsedTime(&ms, e0, e1));
+  *out_us = 1e3f * ms / iters;
+done:
+  (void)hipFree(xin); (void)hipFree(yb); (void)hipFree(wp); (void)hipFree(wf); (void)hipFree(dd); (void)hipFree(slab); (void)hipFree(dw);
+  if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1);
+  return rc;
+}
+extern "C" int pu_bench_conv(int dtype, int mode, int ks, int B, int Cin, int Cout, int H, int W, int iters, float* out_us, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == PU_F16) return bench_conv_t<f16>(mode, ks, B, Cin, Cout, H, W, iters, out_us, s);
+  if (dtype == PU_BF16) return bench_conv_t<bf16>(mode, ks, B, Cin, Cout, H, W, iters, out_us, s);
+  if (dtype == PU_F32) return bench_conv_t<float>(mode, ks, B, Cin, Cout, H, W, iters, out_us, s);
+  return PU_ERR_INVALID;
 }
 
 extern "C" int pu_op_gnsilu(int dtype, int resample, int B, int C, int H, int W, const float* x, const float* gamma, const float* beta,

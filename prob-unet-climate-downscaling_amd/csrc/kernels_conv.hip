@@ -101,7 +101,9 @@ constexpr int KC = 32;     // channels staged per K chunk
 
 // ------------------------------------------------------------------ forward / dgrad implicit GEMM
 // Block = 64*WM*WN threads; pixel tile TH x TW (BM = TH*TW pixels, BM/WM per wave in 32-pixel MFMA columns);
-// cout tile BN = 32*NTN*WN.
+// cout tile BN = 32*NTN*WN.  K loop over 32-channel chunks: the global loads of chunk c+1 are issued into registers
+// before the MFMAs of chunk c (register prefetch), the 9 taps x K-steps of a chunk are fully unrolled so that the LDS
+// fragment reads of the next MFMA group overlap the current one.
 template <typename T, int KS, int TH, int TW, int WM, int WN, int NTN>
 __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs a) {
   typedef MM<T> M;
@@ -115,6 +117,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs a) {
   constexpr int KCP = KC + M::PAD;
   constexpr int VEC = ET<T>::VEC;
   constexpr int CV = KC / VEC;
+  constexpr int NVI_TOT = IH * IW * CV, NVI = (NVI_TOT + NT - 1) / NT;
+  constexpr int NVW_TOT = BN * TAPS * CV, NVW = (NVW_TOT + NT - 1) / NT;
+  constexpr int KSTEPS = KC / M::KSTEP;
   static_assert(BM % (32 * WM) == 0, "pixel tile");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -144,6 +149,53 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // ---- per-thread staging plan (chunk independent): global element offsets (-1 = zero fill) and LDS offsets
+  long gi[NVI]; int li[NVI]; int ci_[NVI];
+#pragma unroll
+  for (int k = 0; k < NVI; ++k) {
+    const int i = tid + k * NT;
+    gi[k] = -1; li[k] = -1; ci_[k] = 0;
+    if (i < NVI_TOT) {
+      const int pix = i / CV, cv = i - pix * CV;
+      const int hy = pix / IW, hx = pix - hy * IW;
+      const int gy = ty0 + hy - PADP, gx = tx0 + hx - PADP;
+      li[k] = pix * KCP + cv * VEC; ci_[k] = cv * VEC;
+      if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) gi[k] = ((long)(b * a.H + gy) * a.W + gx) * a.in_ld + cv * VEC;
+    }
+  }
+  long gw[NVW]; int lw[NVW];
+#pragma unroll
+  for (int k = 0; k < NVW; ++k) {
+    const int i = tid + k * NT;
+    gw[k] = -1; lw[k] = -1;
+    if (i < NVW_TOT) {
+      const int cv = i % CV;
+      const int t = (i / CV) % TAPS;
+      const int n = i / (CV * TAPS);
+      lw[k] = (t * BN + n) * KCP + cv * VEC;
+      if (n0 + n < a.cout_pk) gw[k] = ((long)(n0 + n) * TAPS + t) * a.cin_pk + cv * VEC;
+    }
+  }
+  V16 ri[NVI], rw[NVW];
+  auto gload = [&](int c0) {
+#pragma unroll
+    for (int k = 0; k < NVI; ++k) {
+      ri[k] = zero16();
+      if (gi[k] >= 0 && c0 + ci_[k] < a.Cin) ri[k] = *reinterpret_cast<const V16*>(in + gi[k] + c0);
+    }
+#pragma unroll
+    for (int k = 0; k < NVW; ++k) {
+      rw[k] = zero16();
+      if (gw[k] >= 0) rw[k] = *reinterpret_cast<const V16*>(wpk + gw[k] + c0);
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int k = 0; k < NVI; ++k) if (li[k] >= 0) lds_store_vec<T>(sIn + li[k], ri[k]);
+#pragma unroll
+    for (int k = 0; k < NVW; ++k) if (lw[k] >= 0) lds_store_vec<T>(sW + lw[k], rw[k]);
+  };
+
   // per-lane LDS bases of the B (pixel) fragments, tap (0,0)
   int pbase[NTM];
 #pragma unroll
@@ -153,46 +205,29 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs a) {
   }
   const int wrow = (wn * NTN * 32 + (l & 31)) * KCP;
 
+  gload(0);
   for (int c0 = 0; c0 < a.cin_pk; c0 += KC) {
+    __syncthreads();                               // every wave finished reading the previous chunk
+    lstore();
     __syncthreads();
-    // ---- stage input halo tile (zero fill outside the image / beyond Cin)
-    for (int i = tid; i < IH * IW * CV; i += NT) {
-      const int pix = i / CV, cv = i - pix * CV;
-      const int hy = pix / IW, hx = pix - hy * IW;
-      const int gy = ty0 + hy - PADP, gx = tx0 + hx - PADP;
-      const int ci = c0 + cv * VEC;
-      V16 v = zero16();
-      if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && ci < a.Cin)
-        v = *reinterpret_cast<const V16*>(in + ((size_t)(b * a.H + gy) * a.W + gx) * a.in_ld + ci);
-      lds_store_vec<T>(sIn + pix * KCP + cv * VEC, v);
-    }
-    // ---- stage weight tile [tap][cout][KC]
-    for (int i = tid; i < BN * TAPS * CV; i += NT) {
-      const int cv = i % CV;
-      const int t = (i / CV) % TAPS;
-      const int n = i / (CV * TAPS);
-      V16 v = zero16();
-      if (n0 + n < a.cout_pk)
-        v = *reinterpret_cast<const V16*>(wpk + ((size_t)(n0 + n) * TAPS + t) * a.cin_pk + c0 + cv * VEC);
-      lds_store_vec<T>(sW + (t * BN + n) * KCP + cv * VEC, v);
-    }
-    __syncthreads();
-    int kreal = a.Cin - c0; if (kreal > KC) kreal = KC;
-    const int ksteps = (kreal + M::KSTEP - 1) / M::KSTEP;
+    if (c0 + KC < a.cin_pk) gload(c0 + KC);        // in flight during the MFMAs below
+    if (c0 < a.Cin) {
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t) {
-      const int toff = ((t / KS) * IW + (t % KS)) * KCP;
-      const T* wt = sW + t * BN * KCP + wrow;
-      for (int kk = 0; kk < ksteps; ++kk) {
-        typename M::Frag fa[NTN], fb[NTM];
+      for (int t = 0; t < TAPS; ++t) {
+        const int toff = ((t / KS) * IW + (t % KS)) * KCP;
+        const T* wt = sW + t * BN * KCP + wrow;
 #pragma unroll
-        for (int i = 0; i < NTN; ++i) fa[i] = M::ld(wt + i * 32 * KCP + kk * M::KSTEP, l);
+        for (int kk = 0; kk < KSTEPS; ++kk) {
+          typename M::Frag fa[NTN], fb[NTM];
 #pragma unroll
-        for (int j = 0; j < NTM; ++j) fb[j] = M::ld(sIn + pbase[j] + toff + kk * M::KSTEP, l);
+          for (int i = 0; i < NTN; ++i) fa[i] = M::ld(wt + i * 32 * KCP + kk * M::KSTEP, l);
 #pragma unroll
-        for (int i = 0; i < NTN; ++i)
+          for (int j = 0; j < NTM; ++j) fb[j] = M::ld(sIn + pbase[j] + toff + kk * M::KSTEP, l);
 #pragma unroll
-          for (int j = 0; j < NTM; ++j) acc[i][j] = M::mfma(fa[i], fb[j], acc[i][j]);
+          for (int i = 0; i < NTN; ++i)
+#pragma unroll
+            for (int j = 0; j < NTM; ++j) acc[i][j] = M::mfma(fa[i], fb[j], acc[i][j]);
+        }
       }
     }
   }
@@ -237,6 +272,193 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs a) {
   }
 }
 
+// ------------------------------------------------------------------ conv3: cout-split waves, weights straight to registers
+// 16-bit only.  Block = 4 waves; wave (wm, wn) owns NTM 32-pixel columns x ONE 32-cout row tile, so its A (weight)
+// fragments are private: they are read from the fragment-major packed buffer with one fully coalesced 1-KiB load per
+// (tap, k-step) directly into VGPRs (no LDS, no duplicate staging), and the registers of chunk c are refilled with
+// chunk c+1 right after their last MFMA (prefetch distance = one whole chunk).  Only the 3x3 input halo tile goes
+// through LDS: double-buffered, register-prefetched, one barrier per 32-channel chunk.
+template <typename T, int KS, int TH, int TW, int WM, int WN>
+__global__ __launch_bounds__(256) void conv3_kernel(ConvArgs a) {
+  typedef MM<T> M;
+  constexpr int NT = 256;
+  constexpr int BM = TH * TW;
+  constexpr int NTM = BM / (32 * WM);
+  constexpr int BN = 32 * WN;
+  constexpr int TAPS = KS * KS, PADP = KS / 2;
+  constexpr int IH = TH + 2 * PADP, IW = TW + 2 * PADP;
+  constexpr int KCP = KC + M::PAD;
+  constexpr int CV = KC / 8;
+  constexpr int NVI_TOT = IH * IW * CV, NVI = (NVI_TOT + NT - 1) / NT;
+  constexpr int BUF = IH * IW * KCP;
+  static_assert(WM * WN == 4 && sizeof(T) == 2, "conv3 layout");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* sIn = reinterpret_cast<T*>(smem_raw);                 // [2][IH*IW][KCP]
+
+  const int tid = threadIdx.x, l = tid & 63, wave = tid >> 6;
+  const int wm = wave % WM, wn = wave / WM;
+  const int tiles_x = a.W / TW, tiles_y = a.H / TH;
+  int pt = blockIdx.x;
+  const int tx0 = (pt % tiles_x) * TW; pt /= tiles_x;
+  const int ty0 = (pt % tiles_y) * TH; pt /= tiles_y;
+  const int b = pt;
+  const int ct = blockIdx.y * WN + wn;                     // 32-cout tile of this wave
+  const bool have_w = ct * 32 < a.cout_pk;
+  const int nch = a.cin_pk / KC;
+  const T* in = reinterpret_cast<const T*>(a.in);
+  const T* wfrag = reinterpret_cast<const T*>(a.wpk) + ((size_t)ct * nch) * TAPS * 2 * 512 + l * 8;
+
+  f32x16 acc[NTM];
+#pragma unroll
+  for (int j = 0; j < NTM; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  int gi[NVI], li[NVI];
+#pragma unroll
+  for (int k = 0; k < NVI; ++k) {
+    const int i = tid + k * NT;
+    gi[k] = -1; li[k] = -1;
+    if (i < NVI_TOT) {
+      const int pix = i / CV, cv = i - pix * CV;
+      const int hy = pix / IW, hx = pix - hy * IW;
+      const int gy = ty0 + hy - PADP, gx = tx0 + hx - PADP;
+      li[k] = pix * KCP + cv * 8;
+      if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W) gi[k] = (int)(((long)(b * a.H + gy) * a.W + gx) * a.in_ld + cv * 8);
+    }
+  }
+  V16 ri[NVI];
+  auto gload = [&](int c0) {
+#pragma unroll
+    for (int k = 0; k < NVI; ++k) {
+      ri[k] = zero16();
+      if (gi[k] >= 0 && c0 + (li[k] % KCP) < a.Cin) ri[k] = *reinterpret_cast<const V16*>(in + (size_t)(unsigned)gi[k] + c0);
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int k = 0; k < NVI; ++k) if (li[k] >= 0) *reinterpret_cast<V16*>(sIn + buf * BUF + li[k]) = ri[k];
+  };
+  typename M::Frag fa[TAPS][2];
+  auto wload = [&](int c, int t, int kk) -> typename M::Frag {
+    union { V16 v; typename M::Frag f; } u; u.v = zero16();
+    if (have_w) u.v = *reinterpret_cast<const V16*>(wfrag + ((size_t)(c * TAPS + t) * 2 + kk) * 512);
+    return u.f;
+  };
+  int pbase[NTM];
+#pragma unroll
+  for (int j = 0; j < NTM; ++j) {
+    const int m = (wm * NTM + j) * 32 + (l & 31);
+    pbase[j] = ((m / TW) * IW + (m % TW)) * KCP + 8 * (l >> 5);
+  }
+
+  gload(0);
+#pragma unroll
+  for (int t = 0; t < TAPS; ++t) { fa[t][0] = wload(0, t, 0); fa[t][1] = wload(0, t, 1); }
+  lstore(0);
+  __syncthreads();
+  int cur = 0;
+  for (int c = 0; c < nch; ++c) {
+    const bool more = c + 1 < nch;
+    if (more) gload((c + 1) * KC);
+    const T* sb = sIn + cur * BUF;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+      const int toff = ((t / KS) * IW + (t % KS)) * KCP;
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        typename M::Frag fb[NTM];
+#pragma unroll
+        for (int j = 0; j < NTM; ++j) fb[j] = *reinterpret_cast<const typename M::Frag*>(sb + pbase[j] + toff + kk * 16);
+#pragma unroll
+        for (int j = 0; j < NTM; ++j) acc[j] = M::mfma(fa[t][kk], fb[j], acc[j]);
+        if (more) fa[t][kk] = wload(c + 1, t, kk);
+      }
+    }
+    if (more) lstore(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue (D[row = cout][col = pixel])
+  T* out = reinterpret_cast<T*>(a.out);
+  const T* res = reinterpret_cast<const T*>(a.res);
+#pragma unroll
+  for (int j = 0; j < NTM; ++j) {
+    const int m = (wm * NTM + j) * 32 + (l & 31);
+    const int gy = ty0 + m / TW, gx = tx0 + m % TW;
+    const size_t pix = (size_t)(b * a.H + gy) * a.W + gx;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int co = ct * 32 + 8 * q + 4 * (l >> 5);
+      if (co < a.Cout) {
+        float v[4] = {acc[j][4 * q], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]};
+        if (a.bias) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += a.bias[co + e];
+        }
+        if (res) {
+          float r[4]; load4<T>(res + pix * a.res_ld + co, r);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += r[e];
+        }
+        if (a.accumulate) {
+          float r[4]; load4<T>(out + pix * a.out_ld + co, r);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += r[e];
+        }
+        if (a.relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+        }
+        store4<T>(out + pix * a.out_ld + co, v);
+      }
+    }
+  }
+}
+
+template <typename T, int KS, int TH, int TW, int WM, int WN>
+static hipError_t launch_conv3_cfg(const ConvArgs& a, hipStream_t s) {
+  constexpr int TAPS = KS * KS, PADP = KS / 2;
+  constexpr int IH = TH + 2 * PADP, IW = TW + 2 * PADP, KCP = KC + MM<T>::PAD, BN = 32 * WN;
+  constexpr size_t lds = (size_t)2 * IH * IW * KCP * sizeof(T);
+  auto kern = conv3_kernel<T, KS, TH, TW, WM, WN>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  dim3 grid((unsigned)((a.W / TW) * (a.H / TH) * a.B), (unsigned)cdiv(a.Cout, BN));
+  char tag[128];
+  const bool prof = prof_enabled();
+  if (prof) {
+    snprintf(tag, sizeof tag, "conv3_kernel<%s,%d,%d,%d,%d,%d>", ET<T>::DT == 1 ? "f16" : "bf16", KS, TH, TW, WM, WN);
+    const double px = (double)a.B * a.H * a.W;
+    prof_record(tag, 2.0 * px * a.Cout * (double)a.Cin * TAPS, px * (a.Cin + a.Cout) * sizeof(T) + (double)a.Cout * a.Cin * TAPS * sizeof(T), s, true);
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+  if (prof) prof_record(tag, 0, 0, s, false);
+  return hipGetLastError();
+}
+template <typename T, int KS>
+static hipError_t launch_conv3(const ConvArgs& a, hipStream_t s) {
+  if constexpr (sizeof(T) == 2) {
+    if (a.W % 32 == 0 && a.H % 8 == 0) {
+      if (a.Cout > 64) return launch_conv3_cfg<T, KS, 8, 32, 1, 4>(a, s);
+      if (a.Cout > 32) return launch_conv3_cfg<T, KS, 8, 32, 2, 2>(a, s);
+      return launch_conv3_cfg<T, KS, 8, 32, 4, 1>(a, s);
+    }
+    if (a.W % 16 == 0 && a.H % 16 == 0) {
+      if (a.Cout > 64) return launch_conv3_cfg<T, KS, 16, 16, 1, 4>(a, s);
+      if (a.Cout > 32) return launch_conv3_cfg<T, KS, 16, 16, 2, 2>(a, s);
+      return launch_conv3_cfg<T, KS, 16, 16, 4, 1>(a, s);
+    }
+  }
+  return hipErrorInvalidValue;
+}
+
 template <typename T, int KS, int TH, int TW, int WM, int WN, int NTN>
 static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
   constexpr int TAPS = KS * KS, PADP = KS / 2;
@@ -265,10 +487,15 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
 template <typename T, int KS>
 static hipError_t launch_ks(const ConvArgs& a, hipStream_t s) {
   const bool narrow = a.Cout <= 32;
-  if (a.W % 32 == 0 && a.H % 8 == 0)
+  const bool wide = sizeof(T) == 2 && a.Cout >= 128;
+  if (a.W % 32 == 0 && a.H % 8 == 0) {
+    if constexpr (sizeof(T) == 2) { if (wide) return launch_cfg<T, KS, 8, 32, 4, 1, 4>(a, s); }
     return narrow ? launch_cfg<T, KS, 8, 32, 4, 1, 1>(a, s) : launch_cfg<T, KS, 8, 32, 4, 1, 2>(a, s);
-  if (a.W % 16 == 0 && a.H % 16 == 0)
+  }
+  if (a.W % 16 == 0 && a.H % 16 == 0) {
+    if constexpr (sizeof(T) == 2) { if (wide) return launch_cfg<T, KS, 16, 16, 4, 1, 4>(a, s); }
     return narrow ? launch_cfg<T, KS, 16, 16, 4, 1, 1>(a, s) : launch_cfg<T, KS, 16, 16, 4, 1, 2>(a, s);
+  }
   if (a.W % 8 == 0 && a.H % 8 == 0)
     return launch_cfg<T, KS, 8, 8, 1, 2, 1>(a, s);
   return hipErrorInvalidValue;
@@ -276,6 +503,12 @@ static hipError_t launch_ks(const ConvArgs& a, hipStream_t s) {
 
 template <typename T>
 hipError_t launch_conv(const ConvArgs& a, hipStream_t s) {
+  if (a.frag_layout) {
+    if (!conv_uses_frag_layout((int)sizeof(T), a.H, a.W)) return hipErrorInvalidValue;
+    if (a.taps == 9) return launch_conv3<T, 3>(a, s);
+    if (a.taps == 1) return launch_conv3<T, 1>(a, s);
+    return hipErrorInvalidValue;
+  }
   if (a.taps == 9) return launch_ks<T, 3>(a, s);
   if (a.taps == 1) return launch_ks<T, 1>(a, s);
   return hipErrorInvalidValue;
@@ -478,12 +711,22 @@ __global__ void pack_weights_kernel(const float* __restrict__ params, T* __restr
   const long total = (long)d.rows_pk * d.taps * d.k_pk;
   const float* w = params + d.src_off;
   T* dst = packed + d.dst_off;
+  const bool frag = d.mode >= 2, dgrad = (d.mode & 1) != 0;
+  const int nch = d.k_pk / 32;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int k = (int)(i % d.k_pk);
-    const int t = (int)((i / d.k_pk) % d.taps);
-    const int r = (int)(i / ((long)d.k_pk * d.taps));
+    int k, t, r;
+    if (!frag) {
+      k = (int)(i % d.k_pk); t = (int)((i / d.k_pk) % d.taps); r = (int)(i / ((long)d.k_pk * d.taps));
+    } else {
+      const int e = (int)(i & 7), lane = (int)((i >> 3) & 63);
+      long q = i >> 9;
+      const int kk = (int)(q & 1); q >>= 1;
+      t = (int)(q % d.taps); q /= d.taps;
+      const int c = (int)(q % nch); const int ct = (int)(q / nch);
+      r = ct * 32 + (lane & 31); k = c * 32 + kk * 16 + 8 * (lane >> 5) + e;
+    }
     float v = 0.f;
-    if (d.mode == 0) {
+    if (!dgrad) {
       if (r < d.Cout && k < d.Cin) v = w[((size_t)r * d.Cin + k) * d.taps + t];
     } else {
       if (r < d.Cin && k < d.Cout) v = w[((size_t)k * d.Cin + r) * d.taps + (d.taps - 1 - t)];
@@ -495,7 +738,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ params, T* __restr
 template <typename T>
 hipError_t launch_pack(const float* params, void* packed, const PackDesc* descs_dev, int ndesc, hipStream_t s) {
   if (ndesc == 0) return hipSuccess;
-  hipLaunchKernelGGL(pack_weights_kernel<T>, dim3(64, ndesc), dim3(256), 0, s, params, reinterpret_cast<T*>(packed), descs_dev);
+  hipLaunchKernelGGL(pack_weights_kernel<T>, dim3(288, ndesc), dim3(256), 0, s, params, reinterpret_cast<T*>(packed), descs_dev);
   return hipGetLastError();
 }
 template hipError_t launch_pack<float>(const float*, void*, const PackDesc*, int, hipStream_t);

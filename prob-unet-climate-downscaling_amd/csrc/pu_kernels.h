@@ -13,7 +13,13 @@ struct ConvArgs {
   void* out; int out_ld; int Cout;
   int B, H, W;
   int relu; int accumulate;
+  int frag_layout;                               // 1: wpk is fragment-major (conv3 kernel), see conv_uses_frag_layout()
 };
+// 16-bit convolutions on >= 16-pixel-wide levels run the cout-split kernel whose weights are packed fragment-major:
+//   [cout tile of 32][32-channel chunk][tap][k-step][lane 0..63][8]  =  W[32 ct + (lane & 31)][tap][32 c + 16 kk + 8 (lane >> 5) + e]
+inline bool conv_uses_frag_layout(int elem_size, int H, int W) {
+  return elem_size == 2 && ((W % 32 == 0 && H % 8 == 0) || (W % 16 == 0 && H % 16 == 0));
+}
 struct WgradArgs {
   const void* dy; int dy_ld; int Cout;
   const void* in; int in_ld; int Cin;
@@ -22,7 +28,7 @@ struct WgradArgs {
   float* slab; long slab_floats;                 // split-K partial slabs (16-bit path; required there)
   float inv_scale;                               // parameter gradients are multiplied by this (loss-scale removal)
 };
-struct PackDesc { long src_off; long dst_off; int Cout, Cin, taps, rows_pk, k_pk, mode; };
+struct PackDesc { long src_off; long dst_off; int Cout, Cin, taps, rows_pk, k_pk, mode; };   // mode: 0 fwd, 1 dgrad; +2 = fragment-major
 
 template <typename T> hipError_t launch_conv(const ConvArgs&, hipStream_t);
 template <typename T> hipError_t launch_wgrad(const WgradArgs&, hipStream_t);
