@@ -410,9 +410,13 @@ static int conv_dgrad(pu_ctx* c, const ConvL& L, TV dy, TV dx, int B, int accumu
   CKH(launch_conv<T>(a, s));
   return PU_OK;
 }
+template <typename T> static int conv_bgrad(pu_ctx* c, TV dy, int B, float* d0, float* d1, hipStream_t s);
+// weight gradient (+ bias gradient d0/d1 = column sums of dy when d0 != null)
 template <typename T>
-static int conv_wgrad(pu_ctx* c, const ConvL& L, TV dy, TV in, int B, hipStream_t s) {
+static int conv_wgrad(pu_ctx* c, const ConvL& L, TV dy, TV in, int B, hipStream_t s, float* d0 = nullptr, float* d1 = nullptr) {
   WgradArgs a; memset(&a, 0, sizeof a);
+  if (sizeof(T) == 2) { a.dbias0 = d0; a.dbias1 = d1; }
+  else if (d0) { int r = conv_bgrad<T>(c, dy, B, d0, d1, s); if (r) return r; }
   a.dy = dy.p; a.dy_ld = dy.ld; a.Cout = L.cout; a.in = in.p; a.in_ld = in.ld; a.Cin = L.cin;
   a.dw = G(c, L.w_off); a.B = B; a.H = dy.H; a.W = dy.W; a.taps = L.ks * L.ks;
   a.slab = c->wg_slab; a.slab_floats = c->wg_slab_floats; a.inv_scale = c->inv_scale;
@@ -486,12 +490,10 @@ static int block_bwd(pu_ctx* c, Block& b, int B, int train, uint64_t seed, bool 
   int r;
   TV dout = b.out.g;
   if (!b.is_block) {
-    if ((r = conv_wgrad<T>(c, b.conv0, dout, b.x.v, B, s))) return r;
-    return conv_bgrad<T>(c, dout, B, G(c, b.conv0.b_off), nullptr, s);
+    return conv_wgrad<T>(c, b.conv0, dout, b.x.v, B, s, G(c, b.conv0.b_off), nullptr);
   }
   // conv1
-  if ((r = conv_wgrad<T>(c, b.conv1, dout, b.h1.v, B, s))) return r;
-  if ((r = conv_bgrad<T>(c, dout, B, G(c, b.conv1.b_off), b.skip == SK_CONV ? G(c, b.skipc.b_off) : nullptr, s))) return r;
+  if ((r = conv_wgrad<T>(c, b.conv1, dout, b.h1.v, B, s, G(c, b.conv1.b_off), b.skip == SK_CONV ? G(c, b.skipc.b_off) : nullptr))) return r;
   if ((r = conv_dgrad<T>(c, b.conv1, dout, b.h1.g, B, 0, s))) return r;
   // skip path
   if (b.skip == SK_CONV) {
@@ -510,8 +512,7 @@ static int block_bwd(pu_ctx* c, Block& b, int B, int train, uint64_t seed, bool 
   // norm1 (+scale/shift, dropout) -> c0.g
   if ((r = gn_bwd<T>(c, b.n1, b.c0.v, b.h1.v, b.h1.g, b.c0.g, 0, B, train, seed, s))) return r;
   // conv0
-  if ((r = conv_wgrad<T>(c, b.conv0, b.c0.g, b.a0.v, B, s))) return r;
-  if ((r = conv_bgrad<T>(c, b.c0.g, B, G(c, b.conv0.b_off), nullptr, s))) return r;
+  if ((r = conv_wgrad<T>(c, b.conv0, b.c0.g, b.a0.v, B, s, G(c, b.conv0.b_off), nullptr))) return r;
   if ((r = conv_dgrad<T>(c, b.conv0, b.c0.g, b.a0.g, B, 0, s))) return r;
   // norm0 (+resample) -> x.g   (parameter gradients are needed even when dx is not)
   TV dx = b.x.g; int acc = 0;
@@ -538,8 +539,7 @@ static int unet_backward(pu_ctx* c, hipStream_t s) {
   if (B <= 0) FAIL(PU_ERR_STATE, "U-Net backward without a forward");
   std::fill(c->flags.begin(), c->flags.end(), 0);
   Act& last = c->dec.back().out;
-  if ((r = conv_wgrad<T>(c, c->out_conv, c->feat.g, c->out_a.v, B, s))) return r;
-  if ((r = conv_bgrad<T>(c, c->feat.g, B, G(c, c->out_conv.b_off), nullptr, s))) return r;
+  if ((r = conv_wgrad<T>(c, c->out_conv, c->feat.g, c->out_a.v, B, s, G(c, c->out_conv.b_off), nullptr))) return r;
   if ((r = conv_dgrad<T>(c, c->out_conv, c->feat.g, c->out_a.g, B, 0, s))) return r;
   if ((r = gn_bwd<T>(c, c->out_norm, last.v, c->out_a.v, c->out_a.g, last.g, take_acc(c, last), B, train, seed, s))) return r;
   for (int j = (int)c->dec.size() - 1; j >= 0; --j) if ((r = block_bwd<T>(c, c->dec[j], B, train, seed, true, s))) return r;
@@ -571,8 +571,7 @@ static int gauss_backward(pu_ctx* c, GaussNet& g, hipStream_t s) {
   for (int i = (int)g.convs.size() - 1; i >= 0; --i) {
     TV dy = with_b(g.outs[i].g, B);
     CKH(launch_relu_bwd<T>(with_b(g.outs[i].v, B), dy, s));
-    if ((r = conv_wgrad<T>(c, g.convs[i], g.outs[i].g, g.ins[i].v, B, s))) return r;
-    if ((r = conv_bgrad<T>(c, g.outs[i].g, B, G(c, g.convs[i].b_off), nullptr, s))) return r;
+    if ((r = conv_wgrad<T>(c, g.convs[i], g.outs[i].g, g.ins[i].v, B, s, G(c, g.convs[i].b_off), nullptr))) return r;
     if (i == 0) break;
     if ((r = conv_dgrad<T>(c, g.convs[i], g.outs[i].g, g.ins[i].g, B, 0, s))) return r;
     if (g.pool_before[i]) CKH(launch_maxpool_bwd<T>(with_b(g.outs[i - 1].v, B), with_b(g.ins[i].g, B), with_b(g.outs[i - 1].g, B), s));

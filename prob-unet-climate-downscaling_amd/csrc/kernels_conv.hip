@@ -300,6 +300,8 @@ __global__ __launch_bounds__(256) void conv3_kernel(ConvArgs a) {
   const int wm = wave % WM, wn = wave / WM;
   const int tiles_x = a.W / TW, tiles_y = a.H / TH;
   int pt = blockIdx.x;
+  if ((gridDim.x & 7) == 0) pt = (pt & 7) * (gridDim.x >> 3) + (pt >> 3);   // XCD-aware: each XCD (L2) gets a contiguous band of
+                                                                             // pixel tiles, so halo rows are re-read from its own L2
   const int tx0 = (pt % tiles_x) * TW; pt /= tiles_x;
   const int ty0 = (pt % tiles_y) * TH; pt /= tiles_y;
   const int b = pt;
@@ -422,6 +424,7 @@ template <typename T, int KS, int TH, int TW, int WM, int WN>
 static hipError_t launch_conv3_cfg(const ConvArgs& a, hipStream_t s) {
   constexpr int TAPS = KS * KS, PADP = KS / 2;
   constexpr int IH = TH + 2 * PADP, IW = TW + 2 * PADP, KCP = KC + MM<T>::PAD, BN = 32 * WN;
+  (void)TAPS;
   constexpr size_t lds = (size_t)2 * IH * IW * KCP * sizeof(T);
   auto kern = conv3_kernel<T, KS, TH, TW, WM, WN>;
   static bool attr_done = false;
@@ -450,6 +453,9 @@ static hipError_t launch_conv3(const ConvArgs& a, hipStream_t s) {
       if (a.Cout > 32) return launch_conv3_cfg<T, KS, 8, 32, 2, 2>(a, s);
       return launch_conv3_cfg<T, KS, 8, 32, 4, 1>(a, s);
     }
+    if (a.W % 16 == 0 && a.H % 8 == 0 && a.Cout > 64 &&
+        (long)(a.W / 16) * (a.H / 16) * a.B * cdiv(a.Cout, 128) < 200)      // grid would leave CUs idle: 128-pixel tiles
+      return launch_conv3_cfg<T, KS, 8, 16, 1, 4>(a, s);
     if (a.W % 16 == 0 && a.H % 16 == 0) {
       if (a.Cout > 64) return launch_conv3_cfg<T, KS, 16, 16, 1, 4>(a, s);
       if (a.Cout > 32) return launch_conv3_cfg<T, KS, 16, 16, 2, 2>(a, s);

@@ -127,6 +127,10 @@ __global__ __launch_bounds__(256) void conv_wgrad16_kernel(WgradArgs a) {
   const int g = l >> 4, h = l >> 5, q = (l & 15) >> 2, p = l & 3;
   const int cb = 16 * (g & 1) + 4 * p;
 
+  // fused bias gradient (ci-tile 0 blocks): thread (co = tid & 63, quarter = tid >> 6) sums its pixels of every dy tile
+  const bool do_bias = a.dbias0 != nullptr && blockIdx.z == 0;
+  float bsum = 0.f;
+
   int tile = blockIdx.x;
   int cur = 0;
   if (tile < ntiles) { gload(tile); lstore(0); }
@@ -151,9 +155,27 @@ __global__ __launch_bounds__(256) void conv_wgrad16_kernel(WgradArgs a) {
         }
       }
     }
+    if (do_bias) {
+      const uint16_t* col = lds + cur * BUF + (((tid & 63) >> 5) * BM) * 32 + (tid & 31);
+#pragma unroll 8
+      for (int pp = (tid >> 6) * (BM / 4); pp < ((tid >> 6) + 1) * (BM / 4); ++pp) {
+        T v; *reinterpret_cast<uint16_t*>(&v) = col[pp * 32];
+        bsum += ET<T>::ld(&v);
+      }
+    }
     if (nxt < ntiles) lstore(cur ^ 1);
     __syncthreads();
     cur ^= 1;
+  }
+  if (do_bias) {                                  // combine the 4 pixel quarters, one partial row per split
+    float* red = reinterpret_cast<float*>(smem_raw);
+    red[tid] = bsum;
+    __syncthreads();
+    if (tid < 64) {
+      const int cout_pad_b = gridDim.y * WBCO;
+      float* bslab = a.slab + (size_t)gridDim.x * TAPS * cout_pad_b * (gridDim.z * BCI) + (size_t)blockIdx.x * cout_pad_b;
+      bslab[co0 + tid] = (red[tid] + red[tid + 64]) + (red[tid + 128] + red[tid + 192]);
+    }
   }
 
   // ---- partial tile -> slab [split][tap][cout_pad][cin_pad] (cin contiguous: 128-byte coalesced rows)
@@ -176,9 +198,25 @@ __global__ __launch_bounds__(256) void conv_wgrad16_kernel(WgradArgs a) {
 // dw[co][ci][tap] += inv_scale * sum_s slab[s][tap][co][ci]   (fixed order -> reproducible)
 // block = 64 consecutive elements x 4 split lanes (coalesced 256-byte rows per split), LDS combine
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int split, int taps, int cout_pad, int cin_pad, int Cout, int Cin,
-                                                            float* __restrict__ dw, float inv_scale) {
+                                                            float* __restrict__ dw, float inv_scale, float* db0, float* db1) {
   __shared__ float red[4][64];
   const long total = (long)taps * Cout * Cin;
+  const long nwb = (total + 63) / 64;
+  if (blockIdx.x >= nwb) {                       // bias rows: slab tail [split][cout_pad]
+    const int co = (int)(blockIdx.x - nwb) * 64 + (threadIdx.x & 63);
+    const int lane = threadIdx.x >> 6;
+    const float* bs = slab + (size_t)split * taps * cout_pad * cin_pad;
+    float s = 0.f;
+    if (co < Cout) for (int k = lane; k < split; k += 4) s += bs[(size_t)k * cout_pad + co];
+    red[lane][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (lane == 0 && co < Cout) {
+      const float v = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x])) * inv_scale;
+      db0[co] += v;
+      if (db1) db1[co] += v;
+    }
+    return;
+  }
   const long i = (long)blockIdx.x * 64 + (threadIdx.x & 63);
   const int lane = threadIdx.x >> 6;
   float s = 0.f;
@@ -217,8 +255,8 @@ static hipError_t launch_wg16(const WgradArgs& a, hipStream_t s) {
   }
   const int ntiles = (a.W / TW) * (a.H / TH) * a.B;
   const int gy = cdiv(a.Cout, WBCO), gz = cdiv(a.Cin, BCI);
-  const long per_split = (long)TAPS * gy * WBCO * gz * BCI;
-  int split = cdiv(768, gy * gz);                        // ~3 blocks per CU over the chip
+  const long per_split = (long)TAPS * gy * WBCO * gz * BCI + (long)gy * WBCO;   // + one bias row
+  int split = cdiv(512, gy * gz);                        // ~2 blocks per CU over the chip
   if (split > ntiles) split = ntiles;
   if ((long)split * per_split > a.slab_floats) split = (int)(a.slab_floats / per_split);
   if (split < 1) return hipErrorInvalidValue;
@@ -233,8 +271,9 @@ static hipError_t launch_wg16(const WgradArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(kern, dim3(split, gy, gz), dim3(256), lds, s, b);
   if (prof) prof_record(tag, 0, 0, s, false);
   const long total = (long)TAPS * a.Cout * a.Cin;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, s, a.slab, split, TAPS,
-                     gy * WBCO, gz * BCI, a.Cout, a.Cin, a.dw, a.inv_scale);
+  const unsigned nbias_blocks = a.dbias0 ? (unsigned)cdiv(a.Cout, 64) : 0u;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64) + nbias_blocks), dim3(256), 0, s, a.slab, split, TAPS,
+                     gy * WBCO, gz * BCI, a.Cout, a.Cin, a.dw, a.inv_scale, a.dbias0, a.dbias1);
   return hipGetLastError();
 }
 

@@ -27,6 +27,7 @@ struct WgradArgs {
   int B, H, W; int taps;
   float* slab; long slab_floats;                 // split-K partial slabs (16-bit path; required there)
   float inv_scale;                               // parameter gradients are multiplied by this (loss-scale removal)
+  float* dbias0; float* dbias1;                  // optional (16-bit path): bias gradient(s) = column sums of dy, ADDED into
 };
 struct PackDesc { long src_off; long dst_off; int Cout, Cin, taps, rows_pk, k_pk, mode; };   // mode: 0 fwd, 1 dgrad; +2 = fragment-major
 
