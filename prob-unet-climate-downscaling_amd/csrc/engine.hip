@@ -3,6 +3,7 @@
 // (src/networks.py:134-333) of the reference; see include/probunet.h for the boundary.
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <string>
@@ -73,6 +74,8 @@ struct pu_ctx {
   int unet_B = 0, unet_train = 0; uint64_t unet_seed = 0;
   int max_gn_c = 0;
   float inv_scale = 1.f;            // 1 / (loss scale) applied to every parameter-gradient write of the current backward
+  // weight-gradient kernels (MFMA-bound) run on a side stream, overlapping the HBM-bound dgrad -> GroupNorm-backward chain
+  hipStream_t side = nullptr, side2 = nullptr; std::vector<hipEvent_t> evs; size_t ev_next = 0; bool side_dirty = false; bool use_side = true;
 };
 
 static std::string g_create_err;
@@ -410,6 +413,42 @@ static int conv_dgrad(pu_ctx* c, const ConvL& L, TV dy, TV dx, int B, int accumu
   CKH(launch_conv<T>(a, s));
   return PU_OK;
 }
+// fork: the side stream waits for everything enqueued on `s` so far; returns the stream the weight gradient runs on
+static int fork_side(pu_ctx* c, hipStream_t s, hipStream_t* out) {
+  *out = s;
+  if (!c->use_side) return PU_OK;
+  hipEvent_t e = c->evs[c->ev_next++ % c->evs.size()];
+  CKH(hipEventRecord(e, s));
+  CKH(hipStreamWaitEvent(c->side, e, 0));
+  c->side_dirty = true; *out = c->side;
+  return PU_OK;
+}
+// join: `s` waits for the side stream (called once at the end of every backward)
+static int join_side(pu_ctx* c, hipStream_t s) {
+  if (!c->use_side || !c->side_dirty) return PU_OK;
+  hipEvent_t e = c->evs[c->ev_next++ % c->evs.size()];
+  CKH(hipEventRecord(e, c->side));
+  CKH(hipStreamWaitEvent(s, e, 0));
+  c->side_dirty = false;
+  return PU_OK;
+}
+// second side stream: the two latent encoders run beside the U-Net (forward and backward)
+static int fork2(pu_ctx* c, hipStream_t s, hipStream_t* out) {
+  *out = s;
+  if (!c->use_side || !c->side2) return PU_OK;
+  hipEvent_t e = c->evs[c->ev_next++ % c->evs.size()];
+  CKH(hipEventRecord(e, s));
+  CKH(hipStreamWaitEvent(c->side2, e, 0));
+  *out = c->side2;
+  return PU_OK;
+}
+static int join2(pu_ctx* c, hipStream_t s, hipStream_t s2) {
+  if (s2 == s) return PU_OK;
+  hipEvent_t e = c->evs[c->ev_next++ % c->evs.size()];
+  CKH(hipEventRecord(e, s2));
+  CKH(hipStreamWaitEvent(s, e, 0));
+  return PU_OK;
+}
 template <typename T> static int conv_bgrad(pu_ctx* c, TV dy, int B, float* d0, float* d1, hipStream_t s);
 // weight gradient (+ bias gradient d0/d1 = column sums of dy when d0 != null)
 template <typename T>
@@ -420,7 +459,9 @@ static int conv_wgrad(pu_ctx* c, const ConvL& L, TV dy, TV in, int B, hipStream_
   a.dy = dy.p; a.dy_ld = dy.ld; a.Cout = L.cout; a.in = in.p; a.in_ld = in.ld; a.Cin = L.cin;
   a.dw = G(c, L.w_off); a.B = B; a.H = dy.H; a.W = dy.W; a.taps = L.ks * L.ks;
   a.slab = c->wg_slab; a.slab_floats = c->wg_slab_floats; a.inv_scale = c->inv_scale;
-  CKH(launch_wgrad<T>(a, s));
+  hipStream_t ws = s;
+  if (sizeof(T) == 2) { int r = fork_side(c, s, &ws); if (r) return r; }
+  CKH(launch_wgrad<T>(a, ws));
   return PU_OK;
 }
 static int bias_chunks(long npix) { long n = npix / 256; if (n < 1) n = 1; if (n > 256) n = 256; return (int)n; }
@@ -626,12 +667,22 @@ int pu_create(const pu_config* cfg, int device, pu_ctx** out) {
   if ((e = hipMemcpy(c->descs_dev, c->descs.data(), c->descs.size() * sizeof(PackDesc), hipMemcpyHostToDevice)) != hipSuccess) {
     c->err = "hipMemcpy(descs)"; (void)hipFree(c->arena); (void)hipFree(c->packed); (void)hipFree(c->descs_dev); return bail(PU_ERR_HIP);
   }
+  if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) c->side = nullptr;
+  if (hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking) != hipSuccess) c->side2 = nullptr;
+  if (c->side) {
+    c->evs.resize(256);
+    for (auto& e : c->evs) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { c->use_side = false; e = nullptr; }
+  } else c->use_side = false;
+  if (getenv("PU_NO_SIDE_STREAM") || c->dt == PU_F32) c->use_side = false;   // the fp32 parity path shares scratch (bias_part) and stays serial
   *out = c;
   return PU_OK;
 }
 
 int pu_destroy(pu_ctx* c) {
   if (!c) return PU_OK;
+  for (auto e : c->evs) if (e) (void)hipEventDestroy(e);
+  if (c->side) (void)hipStreamDestroy(c->side);
+  if (c->side2) (void)hipStreamDestroy(c->side2);
   if (c->arena) (void)(void)hipFree(c->arena);
   if (c->packed) (void)(void)hipFree(c->packed);
   if (c->descs_dev) (void)(void)hipFree(c->descs_dev);
@@ -706,7 +757,8 @@ int pu_unet_bwd(pu_ctx* c, const float* dfeat, void* stream) {
     c->inv_scale = 1.f;
     const int F = c->cfg.num_filters[0]; const long HW = (long)c->cfg.H * c->cfg.W;
     CKH(launch_nchw_to_nhwc<T>(dfeat, (long)F * HW, F, nullptr, 0, with_b(c->feat.g, B), s));
-    return unet_backward<T>(c, s);
+    int q = unet_backward<T>(c, s); if (q) return q;
+    return join_side(c, s);
   });
 }
 
@@ -744,7 +796,7 @@ int pu_gauss_bwd(pu_ctx* c, int which, const float* dmu, const float* dls, void*
   const size_t n = (size_t)g.lastB * c->cfg.latent_dim * sizeof(float);
   CKH(hipMemcpyAsync(g.dmu, dmu, n, hipMemcpyDeviceToDevice, s));
   CKH(hipMemcpyAsync(g.dls, dls, n, hipMemcpyDeviceToDevice, s));
-  return dispatch(c, [&](auto t) -> int { typedef decltype(t) T; return gauss_backward<T>(c, g, s); });
+  return dispatch(c, [&](auto t) -> int { typedef decltype(t) T; int q = gauss_backward<T>(c, g, s); if (q) return q; return join_side(c, s); });
 }
 
 int pu_fcomb_fwd(pu_ctx* c, const float* feat, int64_t bstride, const float* z, float* out, int B, void* stream) {
@@ -815,9 +867,12 @@ int pu_elbo_fwd_bwd(pu_ctx* c, const float* x, const float* target, const float*
     int q;
     CKH(launch_nchw_to_nhwc<T>(x, (long)ci * HW, ci, nullptr, 0, with_b(c->x_in.v, B), s));
     CKH(launch_nchw_to_nhwc<T>(x, (long)ci * HW, ci, target, Co, with_b(c->xy_in.v, B), s));
+    hipStream_t s2;
+    if ((q = fork2(c, s, &s2))) return q;
+    if ((q = gauss_forward<T>(c, c->prior, B, s2))) return q;
+    if ((q = gauss_forward<T>(c, c->post, B, s2))) return q;
     if ((q = unet_forward<T>(c, B, train, seed, s))) return q;
-    if ((q = gauss_forward<T>(c, c->prior, B, s))) return q;
-    if ((q = gauss_forward<T>(c, c->post, B, s))) return q;
+    if ((q = join2(c, s, s2))) return q;
     CKH(hipMemsetAsync(c->scal, 0, PU_NUM_SCALARS * sizeof(float), s));
     LatentArgs la; memset(&la, 0, sizeof la);
     la.mu_q = c->post.mu; la.ls_q = c->post.ls; la.mu_p = c->prior.mu; la.ls_p = c->prior.ls; la.eps = eps; la.z = c->z;
@@ -842,9 +897,12 @@ int pu_elbo_fwd_bwd(pu_ctx* c, const float* x, const float* target, const float*
     lb.f = la; lb.dz = c->dz; lb.beta1 = beta1 * S; lb.beta2 = l1 ? beta2 * S : 0.f;
     lb.dmu_q = c->post.dmu; lb.dls_q = c->post.dls; lb.dmu_p = c->prior.dmu; lb.dls_p = c->prior.dls;
     CKH(launch_latent_bwd(lb, s));
-    if ((q = gauss_backward<T>(c, c->post, s))) return q;
-    if ((q = gauss_backward<T>(c, c->prior, s))) return q;
-    return unet_backward<T>(c, s);
+    if ((q = fork2(c, s, &s2))) return q;
+    if ((q = gauss_backward<T>(c, c->post, s2))) return q;
+    if ((q = gauss_backward<T>(c, c->prior, s2))) return q;
+    if ((q = unet_backward<T>(c, s))) return q;
+    if ((q = join2(c, s, s2))) return q;
+    return join_side(c, s);
   });
 }
 
