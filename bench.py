@@ -62,38 +62,58 @@ def build_model(cfg, dtype, device):
 
 
 def cpu_baseline(cfg, seconds_budget=25.0):
-    """The oracle (kind "port": torch-CPU fp32 restatement, validated against the reference's golden vectors) on a bounded
-    sample of the same workload: cfg3 shapes, M as in the bench, batch 1, fwd+bwd, dropout masks injected."""
+    """The oracle (kind "port": torch-CPU fp32 restatement, validated against the reference's golden vectors) on a BOUNDED
+    sample of the same workload: the cfg3 network and ELBO (M as in the bench, dropout masks injected) on ONE 64x64 crop
+    (1/16 of a 256x256 field pair; the network is fully convolutional so cost is proportional to pixels), fwd+bwd.
+    The reported value is converted to 256x256 field-pairs/s (crop rate / 16)."""
     from oracle import probunet_oracle as O
     from tests.filler import fill_state
-    cores = os.cpu_count() or 1
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except Exception:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(16, avail))                      # the GPU box grants a 16-CPU share per GPU
     torch.set_num_threads(cores)
     oc = O.Config(cfg["input_channels"], cfg["num_classes"], cfg["latent_dim"], cfg["num_filters"], cfg["model_channels"], cfg["channel_mult"])
     P = fill_state(O.param_shapes(oc))
-    B = 1
-    x, y = synthetic_fields(B, cfg["input_channels"], cfg["num_classes"], cfg["H"], cfg["W"], 99, "cpu")
+    B, crop = 1, 64
+    frac = (crop * crop) / float(cfg["H"] * cfg["W"])
+    x, y = synthetic_fields(B, cfg["input_channels"], cfg["num_classes"], crop, crop, 99, "cpu")
     eps = torch.randn(cfg["M"], B, cfg["latent_dim"])
     enc, dec = O.unet_layout(oc)
     times = []
     t_all = time.time()
-    for it in range(4):
+    for it in range(6):
         masks = {}
         for b in enc + dec:
             if b.kind == "block":
                 lv = int(b.name.split(".")[2].split("x")[0])
-                r = cfg["H"] * lv // 128
+                r = crop * lv // 128
                 masks[b.name] = (torch.rand(B, b.cout, r, r) >= oc.dropout).float()
         t0 = time.time()
         O.elbo_with_grads(P, oc, x, y, eps, beta0=1.0, beta1=1.0, drop_masks=masks)
         dt = time.time() - t0
+        print(f"[cpu_baseline] step {it}: {dt:.2f} s", file=sys.stderr, flush=True)
         if it > 0:
             times.append(dt)
         if time.time() - t_all > seconds_budget and times:
             break
     med = sorted(times)[len(times) // 2]
-    return dict(value=B / med, unit="field-pairs/s", cores=cores, kind="port",
-                sample=f"cfg3 shapes (4->1, 256x256, depth 5, L=12, M={cfg['M']}), batch 1, fp32 torch-CPU oracle fwd+bwd, "
-                       f"{len(times)} timed step(s) after 1 warm-up, median {med:.2f} s/step")
+    return dict(value=round(B * frac / med, 4), unit="field-pairs/s", cores=cores, kind="port",
+                sample=f"cfg3 network + afCRPS-ELBO M={cfg['M']} fwd+bwd, fp32 torch-CPU oracle, batch 1, one {crop}x{crop} crop "
+                       f"(= {frac:.4f} of a 256x256 pair; value = crop rate x {frac:.4f}), {len(times)} timed step(s) after 1 warm-up, "
+                       f"median {med:.2f} s per crop step, {cores} threads")
+
+
+def pmc_traffic(kernel_tag):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/r1_pmc_traffic.json:
+    FETCH_SIZE x 2 (gfx950 correction, MI355X_MICROARCH.md §HBM) + WRITE_SIZE, KiB -> bytes).  None if not collected."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as f:
+            t = json.load(f)
+        return t.get(kernel_tag, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
 
 
 def main():
@@ -166,9 +186,12 @@ def main():
     roofline = None
     fwd_flops = model.elbo_fwd_flops(cfg["batch"], cfg["M"])
     if rank == 0:
+        lib.pu_set_overlap(model._ctx, 0)            # serial kernels: durations not inflated by co-running side-stream kernels
+        step(); torch.cuda.synchronize()
         lib.pu_profile_enable(1)
         step(); torch.cuda.synchronize()
         lib.pu_profile_enable(0)
+        lib.pu_set_overlap(model._ctx, 1)
         ents = (L.PuProfEntry * 64)()
         n = lib.pu_profile_collect(ents, 64)
         rows = [dict(name=ents[i].name.decode(), launches=ents[i].launches, ms=ents[i].ms, flops=ents[i].flops, bytes=ents[i].bytes) for i in range(n)]
@@ -178,7 +201,7 @@ def main():
             achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
             peak = PEAK[args.dtype] / 1e12
             roofline = dict(bound="mfma", kernel=d["name"], achieved=round(achieved, 2), peak=peak, unit="TFLOP/s",
-                            frac=round(achieved / peak, 4), traffic=None, launches_per_step=d["launches"],
+                            frac=round(achieved / peak, 4), traffic=pmc_traffic(d["name"]), launches_per_step=d["launches"],
                             avg_launch_us=round(1e3 * d["ms"] / d["launches"], 2),
                             flops_per_launch=d["flops"] / d["launches"],
                             algorithmic_bytes_per_launch=d["bytes"] / d["launches"],

@@ -129,6 +129,9 @@ double pu_elbo_fwd_flops(pu_ctx*, int B, int M);
  * pu_profile_enable(1) ... run steps ... pu_profile_collect() waits for the recorded events and returns entries. */
 typedef struct { char name[128]; long launches; double ms; double flops; double bytes; } pu_prof_entry;
 int pu_profile_enable(int on);
+/* Side-stream overlap (weight gradients / latent encoders beside the U-Net chain) on or off; default on for f16/bf16.
+ * bench.py switches it off for the per-kernel roofline step so that kernel durations are not inflated by co-running kernels. */
+int pu_set_overlap(pu_ctx* ctx, int on);
 int pu_profile_collect(pu_prof_entry* out, int max_entries);
 
 /* ---- single-op entry points (used by tests/ to pin each kernel against a torch fp32 reference) ----------- */

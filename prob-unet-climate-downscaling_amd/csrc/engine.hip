@@ -697,6 +697,11 @@ int pu_param_table(pu_ctx* c, const pu_param_desc** out, int* n) {
 }
 int64_t pu_param_count(pu_ctx* c) { return c ? c->nparams : -1; }
 int pu_profile_enable(int on) { prof_enable(on != 0); return PU_OK; }
+int pu_set_overlap(pu_ctx* c, int on) {
+  if (!c) return PU_ERR_INVALID;
+  c->use_side = on != 0 && c->side && c->side2 && c->dt != PU_F32 && !getenv("PU_NO_SIDE_STREAM");
+  return PU_OK;
+}
 int pu_profile_collect(pu_prof_entry* out, int max_entries) {
   static_assert(sizeof(pu_prof_entry) == sizeof(ProfEntry), "pu_prof_entry layout");
   return out ? prof_collect(reinterpret_cast<ProfEntry*>(out), max_entries) : 0;

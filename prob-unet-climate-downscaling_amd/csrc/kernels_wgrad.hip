@@ -256,7 +256,8 @@ static hipError_t launch_wg16(const WgradArgs& a, hipStream_t s) {
   const int ntiles = (a.W / TW) * (a.H / TH) * a.B;
   const int gy = cdiv(a.Cout, WBCO), gz = cdiv(a.Cin, BCI);
   const long per_split = (long)TAPS * gy * WBCO * gz * BCI + (long)gy * WBCO;   // + one bias row
-  int split = cdiv(512, gy * gz);                        // ~2 blocks per CU over the chip
+  int split = cdiv(BCI == 64 ? 256 : 512, gy * gz);      // resident blocks per CU: 1 (85 KB LDS) / 2 (59 KB); fewer, longer
+                                                         // K ranges keep the slab traffic (split x tile) below the operand traffic
   if (split > ntiles) split = ntiles;
   if ((long)split * per_split > a.slab_floats) split = (int)(a.slab_floats / per_split);
   if (split < 1) return hipErrorInvalidValue;
