@@ -116,6 +116,40 @@ def pmc_traffic(kernel_tag):
         return None
 
 
+def bench_sample(args):
+    """BASELINE config 5 (secondary metric): inference-only latent exploration, 256x256, `samples` prior samples per input."""
+    device = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    B = args.batch if args.batch != CFG3["batch"] else 8
+    cfg = dict(CFG3, batch=B, M=args.samples)
+    model = build_model(cfg, args.dtype, device).eval()
+    x, _ = synthetic_fields(B, cfg["input_channels"], cfg["num_classes"], cfg["H"], cfg["W"], 4321, device)
+    for _ in range(args.warmup):
+        model.sample(x, args.samples)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = model.sample(x, args.samples)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    # Fcomb-only rate (features and prior fixed, the inner loop of latent_exploration.py:119-129)
+    with torch.no_grad():
+        feat = model.unet(x[:1])
+        z = torch.randn(args.samples, cfg["latent_dim"], device=device)
+        for _ in range(3):
+            model.fcomb(feat.expand(args.samples, -1, -1, -1), z)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        for _ in range(20):
+            model.fcomb(feat.expand(args.samples, -1, -1, -1), z)
+        torch.cuda.synchronize(); el2 = time.perf_counter() - t1
+    print(json.dumps(dict(metric="prior samples/sec at 256x256 (64 samples per lo-res input)", value=round(B * args.samples * args.steps / el, 1),
+                          unit="samples/s", n_gpus=1, steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * el / args.steps, 3),
+                          higher_is_better=True, scaling="weak", vs_baseline=None, dtype=args.dtype, data="synthetic",
+                          config=dict(workload=f"cfg5: 4->1, 256x256, latent 12, depth-5 U-Net, {B} inputs x {args.samples} prior samples per call "
+                                               "(U-Net + prior once, then the fused Fcomb per sample)",
+                                      fcomb_only_samples_per_s=round(args.samples * 20 / el2, 1)))), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -126,7 +160,12 @@ def main():
     ap.add_argument("--members", type=int, default=CFG3["M"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optimizer", action="store_true", help="time ELBO fwd+bwd only (diagnostic; not the reported metric)")
+    ap.add_argument("--mode", default="train", choices=["train", "sample"],
+                    help="sample = BASELINE config 5: prior samples/s, 64 samples per lo-res input (U-Net + prior once, 64 x Fcomb)")
+    ap.add_argument("--samples", type=int, default=64)
     args = ap.parse_args()
+    if args.mode == "sample":
+        return bench_sample(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -147,7 +186,10 @@ def main():
     model.sync_scalars = False                       # keep the loss scalars on the device: no .item() sync per step
     if world > 1:
         model.enable_data_parallel()
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
+    try:
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-4, fused=True)     # same optimizer as main.py:103, fused multi-tensor kernel
+    except Exception:
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
     x, y = synthetic_fields(cfg["batch"], cfg["input_channels"], cfg["num_classes"], cfg["H"], cfg["W"], 1234 + rank, device)
     t_stamp = torch.zeros(cfg["batch"], 1, device=device)
 

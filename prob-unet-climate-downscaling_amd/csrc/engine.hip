@@ -343,7 +343,7 @@ static int build_plan(pu_ctx* c) {
   c->fc_b2 = add_param(c, "fcomb.layers.4.bias", {Co});
   if (F != 8 && F != 16 && F != 32) FAIL(PU_ERR_INVALID, "num_filters[0]=%d unsupported by the fused Fcomb kernel (8, 16 or 32)", F);
   if (Co > F) FAIL(PU_ERR_INVALID, "num_classes %d > num_filters[0] %d unsupported", Co, F);
-  if (MM_ > 16) FAIL(PU_ERR_INVALID, "max_members %d > 16 unsupported by the fused afCRPS kernel", MM_);
+  if (MM_ > 256) FAIL(PU_ERR_INVALID, "max_members %d > 256 unsupported", MM_);
 
   // ---- scratch
   const long HW = (long)H * W;
@@ -850,6 +850,7 @@ int pu_elbo_fwd_bwd(pu_ctx* c, const float* x, const float* target, const float*
   int r; if ((r = check_B(c, B))) return r;
   if (M < 1 || M > c->cfg.max_members) FAIL(PU_ERR_INVALID, "M=%d outside [1, max_members=%d]", M, c->cfg.max_members);
   if (recon_kind == PU_RECON_AFCRPS && M < 2) FAIL(PU_ERR_INVALID, "M must be at least 2 to compute afCRPS but got M=%d", M);
+  if (recon_kind == PU_RECON_AFCRPS && M > 16) FAIL(PU_ERR_INVALID, "M=%d > 16 unsupported by the fused afCRPS kernel", M);
   if (recon_kind != PU_RECON_AFCRPS && recon_kind != PU_RECON_L1) FAIL(PU_ERR_INVALID, "unknown recon kind %d", recon_kind);
   if (with_backward && !c->grads) FAIL(PU_ERR_STATE, "no gradient buffer bound");
   hipStream_t s = (hipStream_t)stream;

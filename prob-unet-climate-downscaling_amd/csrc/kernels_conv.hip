@@ -13,6 +13,7 @@
 // LDS tiles are [pixel][channel] / [cout][channel] with the channel (K) axis contiguous, so one ds_read_b128 yields
 // a whole 16-bit fragment; the 3x3 halo tile is staged once per 32-channel chunk and reused by all 9 taps.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -279,9 +280,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs a) {
 // chunk c+1 right after their last MFMA (prefetch distance = one whole chunk).  Only the 3x3 input halo tile goes
 // through LDS: double-buffered, register-prefetched, one barrier per 32-channel chunk.
 template <typename T, int KS, int TH, int TW, int WM, int WN>
-__global__ __launch_bounds__(256) void conv3_kernel(ConvArgs a) {
+__global__ __launch_bounds__(64 * WM * WN) void conv3_kernel(ConvArgs a) {
   typedef MM<T> M;
-  constexpr int NT = 256;
+  constexpr int NT = 64 * WM * WN;
   constexpr int BM = TH * TW;
   constexpr int NTM = BM / (32 * WM);
   constexpr int BN = 32 * WN;
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(256) void conv3_kernel(ConvArgs a) {
   constexpr int CV = KC / 8;
   constexpr int NVI_TOT = IH * IW * CV, NVI = (NVI_TOT + NT - 1) / NT;
   constexpr int BUF = IH * IW * KCP;
-  static_assert(WM * WN == 4 && sizeof(T) == 2, "conv3 layout");
+  static_assert(sizeof(T) == 2, "conv3 layout");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* sIn = reinterpret_cast<T*>(smem_raw);                 // [2][IH*IW][KCP]
@@ -331,11 +332,14 @@ __global__ __launch_bounds__(256) void conv3_kernel(ConvArgs a) {
     }
   }
   V16 ri[NVI];
+  // branch-free staging loads: out-of-image / beyond-Cin vectors read a valid dummy address and are zeroed by a select,
+  // so the whole chunk body stays one basic block (the scheduler can then run LDS reads ahead of the MFMAs)
   auto gload = [&](int c0) {
 #pragma unroll
     for (int k = 0; k < NVI; ++k) {
-      ri[k] = zero16();
-      if (gi[k] >= 0 && c0 + (li[k] % KCP) < a.Cin) ri[k] = *reinterpret_cast<const V16*>(in + (size_t)(unsigned)gi[k] + c0);
+      const bool ok = gi[k] >= 0 && c0 + (li[k] % KCP) < a.Cin;
+      const V16 v = *reinterpret_cast<const V16*>(in + (ok ? (size_t)(unsigned)gi[k] + c0 : (size_t)0));
+      ri[k].w[0] = ok ? v.w[0] : 0u; ri[k].w[1] = ok ? v.w[1] : 0u; ri[k].w[2] = ok ? v.w[2] : 0u; ri[k].w[3] = ok ? v.w[3] : 0u;
     }
   };
   auto lstore = [&](int buf) {
@@ -343,9 +347,10 @@ __global__ __launch_bounds__(256) void conv3_kernel(ConvArgs a) {
     for (int k = 0; k < NVI; ++k) if (li[k] >= 0) *reinterpret_cast<V16*>(sIn + buf * BUF + li[k]) = ri[k];
   };
   typename M::Frag fa[TAPS][2];
+  const T* wbase = have_w ? wfrag : reinterpret_cast<const T*>(a.wpk) + l * 8;     // idle waves read tile 0 (never stored)
   auto wload = [&](int c, int t, int kk) -> typename M::Frag {
-    union { V16 v; typename M::Frag f; } u; u.v = zero16();
-    if (have_w) u.v = *reinterpret_cast<const V16*>(wfrag + ((size_t)(c * TAPS + t) * 2 + kk) * 512);
+    union { V16 v; typename M::Frag f; } u;
+    u.v = *reinterpret_cast<const V16*>(wbase + ((size_t)(c * TAPS + t) * 2 + kk) * 512);
     return u.f;
   };
   int pbase[NTM];
@@ -363,6 +368,7 @@ __global__ __launch_bounds__(256) void conv3_kernel(ConvArgs a) {
   int cur = 0;
   for (int c = 0; c < nch; ++c) {
     const bool more = c + 1 < nch;
+    const int cn = more ? c + 1 : c;               // the last chunk harmlessly re-reads its own fragments
     if (more) gload((c + 1) * KC);
     const T* sb = sIn + cur * BUF;
 #pragma unroll
@@ -375,7 +381,7 @@ __global__ __launch_bounds__(256) void conv3_kernel(ConvArgs a) {
         for (int j = 0; j < NTM; ++j) fb[j] = *reinterpret_cast<const typename M::Frag*>(sb + pbase[j] + toff + kk * 16);
 #pragma unroll
         for (int j = 0; j < NTM; ++j) acc[j] = M::mfma(fa[t][kk], fb[j], acc[j]);
-        if (more) fa[t][kk] = wload(c + 1, t, kk);
+        fa[t][kk] = wload(cn, t, kk);
       }
     }
     if (more) lstore(cur ^ 1);
@@ -441,7 +447,7 @@ static hipError_t launch_conv3_cfg(const ConvArgs& a, hipStream_t s) {
     const double px = (double)a.B * a.H * a.W;
     prof_record(tag, 2.0 * px * a.Cout * (double)a.Cin * TAPS, px * (a.Cin + a.Cout) * sizeof(T) + (double)a.Cout * a.Cin * TAPS * sizeof(T), s, true);
   }
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+  hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, a);
   if (prof) prof_record(tag, 0, 0, s, false);
   return hipGetLastError();
 }

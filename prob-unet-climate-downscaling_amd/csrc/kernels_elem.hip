@@ -214,7 +214,46 @@ hipError_t launch_gn_fwd(const GNArgs& a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------ GroupNorm + SiLU backward
-// pass 1: dv = dL/d(pre-activation) written to scratch; per (b, chunk, c): S1 = sum dv, S2 = sum dv * xhat
+// dv = dL/d(pre-activation) = adjoint-resample(dy) * dropout mask * silu'(A x + Bc) is recomputed wherever needed:
+//   pass 1: per (b, chunk, c)  S1 = sum dv, S2 = sum dv * xhat              (reads x, dy; writes nothing else)
+//   pass 2: dx (+)= P dv + Q x + R                                          (reads x, dy; writes dx)
+// i.e. 4 tensor reads + 1 write instead of the 4 + 2 of a stored-dv formulation.
+template <typename T, int RS>
+__device__ __forceinline__ void gn_dv(const GNArgs& f, const TV& dy, int b, int y, int x, long p, int cv, const float* A, const float* Bc,
+                                      const float* xv, float keep, float inv_keep, float* dv) {
+  constexpr int VEC = ET<T>::VEC;
+  const int H = f.x.H, W = f.x.W, C = f.x.C;
+  const long HW = (long)H * W;
+  const T* dyp = reinterpret_cast<const T*>(dy.p);
+  float dh[VEC];
+  if (RS == RS_NONE) {
+    unpack<T>(ldv<T>(dyp + ((long)b * HW + p) * dy.ld + cv * VEC), dh);
+  } else if (RS == RS_DOWN) {
+    unpack<T>(ldv<T>(dyp + (((long)b * (H / 2) + (y >> 1)) * (W / 2) + (x >> 1)) * dy.ld + cv * VEC), dh);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) dh[e] *= 0.25f;
+  } else {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) dh[e] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float t[VEC];
+      unpack<T>(ldv<T>(dyp + (((long)b * (2 * H) + (2 * y + (q >> 1))) * (2 * W) + (2 * x + (q & 1))) * dy.ld + cv * VEC), t);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) dh[e] += t[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    float d = dh[e];
+    if (RS == RS_NONE && f.drop_p > 0.f) {
+      const uint64_t idx = ((uint64_t)b * HW + p) * (uint64_t)C + (uint64_t)(cv * VEC + e);
+      d = hash_uniform(f.drop_seed, f.drop_stream, idx) < keep ? d * inv_keep : 0.f;
+    }
+    dv[e] = d * dsilu_f(A[e] * xv[e] + Bc[e]);
+  }
+}
+
 template <typename T, int RS>
 __global__ __launch_bounds__(256) void gn_bwd_pass1_kernel(GNBwdArgs a) {
   constexpr int VEC = ET<T>::VEC;
@@ -223,13 +262,11 @@ __global__ __launch_bounds__(256) void gn_bwd_pass1_kernel(GNBwdArgs a) {
   const int C = f.x.C, CV = C / VEC, PL = 256 / CV;
   const int tid = threadIdx.x, cv = tid % CV, pl = tid / CV;
   const int chunk = blockIdx.x, b = blockIdx.y;
-  const int H = f.x.H, W = f.x.W;
-  const long HW = (long)H * W;
+  const int W = f.x.W;
+  const long HW = (long)f.x.H * W;
   const long per = (HW + f.nchunk - 1) / f.nchunk;
   const long p0 = (long)chunk * per, p1 = min(HW, p0 + per);
   const T* xp = reinterpret_cast<const T*>(f.x.p);
-  const T* dyp = reinterpret_cast<const T*>(a.dy.p);
-  T* dvp = reinterpret_cast<T*>(a.dv.p);
   const int cpg = C / f.G;
   float A[VEC], Bc[VEC], mean[VEC], rstd[VEC], s1[VEC], s2[VEC];
   const float keep = 1.f - f.drop_p, inv_keep = f.drop_p > 0.f ? 1.f / keep : 1.f;
@@ -244,38 +281,11 @@ __global__ __launch_bounds__(256) void gn_bwd_pass1_kernel(GNBwdArgs a) {
     }
     for (long p = p0 + pl; p < p1; p += PL) {
       const int y = (int)(p / W), x = (int)(p % W);
-      float dh[VEC];
-      if (RS == RS_NONE) {
-        unpack<T>(ldv<T>(dyp + ((long)b * HW + p) * a.dy.ld + cv * VEC), dh);
-      } else if (RS == RS_DOWN) {
-        unpack<T>(ldv<T>(dyp + (((long)b * (H / 2) + (y >> 1)) * (W / 2) + (x >> 1)) * a.dy.ld + cv * VEC), dh);
+      float xv[VEC], dv[VEC];
+      unpack<T>(ldv<T>(xp + ((long)b * HW + p) * f.x.ld + cv * VEC), xv);
+      gn_dv<T, RS>(f, a.dy, b, y, x, p, cv, A, Bc, xv, keep, inv_keep, dv);
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) dh[e] *= 0.25f;
-      } else {
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) dh[e] = 0.f;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float t[VEC];
-          unpack<T>(ldv<T>(dyp + (((long)b * (2 * H) + (2 * y + (q >> 1))) * (2 * W) + (2 * x + (q & 1))) * a.dy.ld + cv * VEC), t);
-#pragma unroll
-          for (int e = 0; e < VEC; ++e) dh[e] += t[e];
-        }
-      }
-      float xv[VEC]; unpack<T>(ldv<T>(xp + ((long)b * HW + p) * f.x.ld + cv * VEC), xv);
-      float dv[VEC];
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) {
-        float d = dh[e];
-        if (RS == RS_NONE && f.drop_p > 0.f) {
-          const uint64_t idx = ((uint64_t)b * HW + p) * (uint64_t)C + (uint64_t)(cv * VEC + e);
-          d = hash_uniform(f.drop_seed, f.drop_stream, idx) < keep ? d * inv_keep : 0.f;
-        }
-        dv[e] = d * dsilu_f(A[e] * xv[e] + Bc[e]);
-        s1[e] += dv[e];
-        s2[e] += dv[e] * (xv[e] - mean[e]) * rstd[e];
-      }
-      stv<T>(dvp + ((long)b * HW + p) * a.dv.ld + cv * VEC, pack<T>(dv));
+      for (int e = 0; e < VEC; ++e) { s1[e] += dv[e]; s2[e] += dv[e] * (xv[e] - mean[e]) * rstd[e]; }
     }
 #pragma unroll
     for (int e = 0; e < VEC; ++e) { buf[(pl * C + cv * VEC + e) * 2] = s1[e]; buf[(pl * C + cv * VEC + e) * 2 + 1] = s2[e]; }
@@ -341,24 +351,28 @@ __global__ void gn_param_grad_kernel(GNBwdArgs a) {
   if (a.dshift) a.dshift[c] += S1;
 }
 
-template <typename T>
+template <typename T, int RS>
 __global__ void gn_bwd_pass2_kernel(GNBwdArgs a) {
   constexpr int VEC = ET<T>::VEC;
   const GNArgs& f = a.f;
-  const int C = f.x.C, CV = C / VEC;
-  const long HW = (long)f.x.H * f.x.W;
+  const int C = f.x.C, CV = C / VEC, W = f.x.W;
+  const long HW = (long)f.x.H * W;
   const long total = (long)f.x.B * HW * CV;
   const T* xp = reinterpret_cast<const T*>(f.x.p);
-  const T* dvp = reinterpret_cast<const T*>(a.dv.p);
   T* dxp = reinterpret_cast<T*>(a.dx.p);
+  const float keep = 1.f - f.drop_p, inv_keep = f.drop_p > 0.f ? 1.f / keep : 1.f;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int cv = (int)(i % CV);
     const long bp = i / CV;
     const int b = (int)(bp / HW);
+    const long p = bp - (long)b * HW;
     const float* cf = a.coef2 + ((long)b * C + cv * VEC) * 3;
-    float xv[VEC], dv[VEC], o[VEC];
+    const float* c1 = f.coef + ((long)b * C + cv * VEC) * 2;
+    float A[VEC], Bc[VEC], xv[VEC], dv[VEC], o[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { A[e] = c1[2 * e]; Bc[e] = c1[2 * e + 1]; }
     unpack<T>(ldv<T>(xp + bp * f.x.ld + cv * VEC), xv);
-    unpack<T>(ldv<T>(dvp + bp * a.dv.ld + cv * VEC), dv);
+    gn_dv<T, RS>(f, a.dy, b, (int)(p / W), (int)(p % W), p, cv, A, Bc, xv, keep, inv_keep, dv);
     if (a.accumulate) unpack<T>(ldv<T>(dxp + bp * a.dx.ld + cv * VEC), o);
     else {
 #pragma unroll
@@ -380,7 +394,9 @@ hipError_t launch_gn_bwd(const GNBwdArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(f.x.B), dim3(256), 0, s, a);
   hipLaunchKernelGGL(gn_param_grad_kernel, dim3(cdiv(f.x.C, 256)), dim3(256), 0, s, a);
   const long total = (long)f.x.B * f.x.H * f.x.W * (f.x.C / ET<T>::VEC);
-  hipLaunchKernelGGL(gn_bwd_pass2_kernel<T>, dim3(ew_grid(total)), dim3(256), 0, s, a);
+  if (f.resample == RS_NONE) hipLaunchKernelGGL((gn_bwd_pass2_kernel<T, RS_NONE>), dim3(ew_grid(total)), dim3(256), 0, s, a);
+  else if (f.resample == RS_DOWN) hipLaunchKernelGGL((gn_bwd_pass2_kernel<T, RS_DOWN>), dim3(ew_grid(total)), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((gn_bwd_pass2_kernel<T, RS_UP>), dim3(ew_grid(total)), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 
