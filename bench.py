@@ -184,6 +184,7 @@ def main():
     cfg = dict(CFG3, batch=args.batch, M=args.members)
     model = build_model(cfg, args.dtype, device)
     model.sync_scalars = False                       # keep the loss scalars on the device: no .item() sync per step
+    torch.manual_seed(1234 + rank)                   # rank-offset reparameterisation noise (dropout seeds are rank-offset inside the model)
     if world > 1:
         model.enable_data_parallel()
     try:

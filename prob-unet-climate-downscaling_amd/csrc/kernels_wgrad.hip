@@ -15,6 +15,7 @@
 //   * each block writes its fp32 partial tile to a slab [split][tap][cout][cin] with coalesced stores; a second kernel
 //     sums the slabs in a fixed order (bitwise reproducible, no float atomics) and adds into the fp32 gradient
 #include <cstdio>
+#include <cstdlib>
 
 #include "pu_kernels.h"
 
@@ -281,6 +282,7 @@ static hipError_t launch_wg16(const WgradArgs& a, hipStream_t s) {
 template <typename T, int KS>
 static hipError_t launch_wg16_ks(const WgradArgs& a, hipStream_t s) {
   const bool wide = a.Cin > 32;
+  if (a.W % 32 == 0 && a.H % 8 == 0 && wide) return launch_wg16<T, KS, 8, 32, 64>(a, s);    // 256-pixel K tiles (152 KB LDS): +4 %
   if (a.W % 32 == 0 && a.H % 4 == 0) return wide ? launch_wg16<T, KS, 4, 32, 64>(a, s) : launch_wg16<T, KS, 4, 32, 32>(a, s);
   if (a.W % 16 == 0 && a.H % 8 == 0) return wide ? launch_wg16<T, KS, 8, 16, 64>(a, s) : launch_wg16<T, KS, 8, 16, 32>(a, s);
   if (a.W % 8 == 0 && a.H % 8 == 0) return wide ? launch_wg16<T, KS, 8, 8, 64>(a, s) : launch_wg16<T, KS, 8, 8, 32>(a, s);

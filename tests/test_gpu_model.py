@@ -235,3 +235,45 @@ def test_f16_static_loss_scale_keeps_tiny_gradients():
     # the closed-form filler network amplifies rounding ~1e4x (torch fp32 vs fp64: 2e-3), so fp16 U-Net gradients agree
     # with the fp32 oracle only to a cosine of ~0.985 with or without the loss scale
     assert num / (den1 ** 0.5 * den2 ** 0.5) > 0.97
+
+
+def test_side_stream_overlap_is_race_free():
+    """The f16/bf16 engines run weight gradients and the latent encoders on side HIP streams (fork/join by events).
+    Same inputs with overlap off and on must give the same loss and gradients (slab reductions are order-fixed; only the
+    Fcomb weight-gradient atomics may differ in the last bits)."""
+    from probunet_amd import _lib as L
+    c = dict(input_channels=4, num_classes=1, latent_dim=6, num_filters=[32, 64, 128], model_channels=32, channel_mult=[1, 2, 4])
+    cfg = oracle_cfg(c)
+    P = filled_params(cfg)
+    x, y = make_fields(8, 4, 1, 64, 64); eps = make_eps(3, 8, 6)
+    res = []
+    for overlap in (0, 1, 1):
+        m = pa.ProbabilisticUNet(4, 1, 6, [32, 64, 128], 32, [1, 2, 4], 0.7, 1.3, 0.0, dtype="f16", init=False)
+        m.load_state_dict(P); m = m.to(DEV).train(); m.dropout = 0.0
+        m._ensure(64, 64, 8, 3)
+        L.lib().pu_set_overlap(m._ctx, overlap)
+        for _ in range(2):                                   # second call reuses every buffer: stale-data hazards would show
+            m.zero_grad()
+            total, _, kl = m.elbo(x.to(DEV), y.to(DEV), None, M=3, eps=eps.to(DEV))
+            total.backward()
+        torch.cuda.synchronize()
+        res.append((float(total.detach()), torch.cat([p.grad.flatten() for p in m.parameters()]).double().cpu()))
+    for k in (1, 2):
+        assert abs(res[k][0] - res[0][0]) <= 1e-6 * abs(res[0][0])
+        rel = float((res[k][1] - res[0][1]).norm() / res[0][1].norm())
+        assert rel < 1e-5, rel
+
+
+def test_bf16_engine_and_posterior_sampling():
+    meta, g = load_golden("mid11")
+    m = build(meta, dtype="bf16", max_members=40).eval()
+    x, y = t(g["x"]).to(DEV), t(g["y"]).to(DEV)
+    with torch.no_grad():
+        eps = torch.randn(40, x.shape[0], 6, device=DEV)
+        out = m.sample(x, 40, target=y, eps=eps)              # posterior samples, n > 16
+        assert out.shape == (x.shape[0], 40, 1, 32, 32) and torch.isfinite(out).all()
+        feat = m.unet(x); q = m.posterior(x, y)
+        z = q.base_dist.loc + q.base_dist.scale * eps[7]
+        assert_close(out[:, 7].cpu(), m.fcomb(feat, z).cpu(), rtol=5e-2, atol=5e-2, what="sample vs sub-modules")
+    with pytest.raises(pa._lib.ProbUNetLibraryError):
+        m.train(); m.elbo(x, y, None, M=17)                    # fused afCRPS kernel supports M <= 16
