@@ -389,41 +389,270 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3_kernel(ConvArgs a) {
     cur ^= 1;
   }
 
-  // ---- epilogue (D[row = cout][col = pixel])
-  T* out = reinterpret_cast<T*>(a.out);
-  const T* res = reinterpret_cast<const T*>(a.res);
+  // ---- epilogue: D[row = cout][col = pixel] -> (+bias) -> wave-private LDS tile [pixel][32 couts] (80-byte rows) ->
+  //      16-byte rows per lane: residual / accumulate / ReLU in the 16-byte domain, fully coalesced 64-byte runs per pixel
+  constexpr int ERS = 40;                                   // staged row stride (elements)
+  T* stage = reinterpret_cast<T*>(smem_raw) + wave * (NTM * 32 * ERS);
+  {
+    float bq[16];
 #pragma unroll
-  for (int j = 0; j < NTM; ++j) {
-    const int m = (wm * NTM + j) * 32 + (l & 31);
-    const int gy = ty0 + m / TW, gx = tx0 + m % TW;
-    const size_t pix = (size_t)(b * a.H + gy) * a.W + gx;
+    for (int r = 0; r < 16; ++r) {
+      const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+      bq[r] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
+    }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int co = ct * 32 + 8 * q + 4 * (l >> 5);
-      if (co < a.Cout) {
-        float v[4] = {acc[j][4 * q], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]};
-        if (a.bias) {
+    for (int j = 0; j < NTM; ++j) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += a.bias[co + e];
-        }
-        if (res) {
-          float r[4]; load4<T>(res + pix * a.res_ld + co, r);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += r[e];
-        }
-        if (a.accumulate) {
-          float r[4]; load4<T>(out + pix * a.out_ld + co, r);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += r[e];
-        }
-        if (a.relu) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
-        }
-        store4<T>(out + pix * a.out_ld + co, v);
+      for (int q = 0; q < 4; ++q) {
+        float v[4] = {acc[j][4 * q] + bq[4 * q], acc[j][4 * q + 1] + bq[4 * q + 1], acc[j][4 * q + 2] + bq[4 * q + 2], acc[j][4 * q + 3] + bq[4 * q + 3]};
+        store4<T>(stage + (j * 32 + (l & 31)) * ERS + 8 * q + 4 * (l >> 5), v);
       }
     }
   }
+  T* out = reinterpret_cast<T*>(a.out);
+  const T* res = reinterpret_cast<const T*>(a.res);
+#pragma unroll
+  for (int it = 0; it < NTM * 2; ++it) {
+    const int i = it * 64 + l;                               // (pixel of the wave, 8-cout chunk)
+    const int pw = i >> 2, ch = i & 3;
+    const int m = wm * NTM * 32 + pw;
+    const int gy = ty0 + m / TW, gx = tx0 + m % TW;
+    const size_t pix = (size_t)(b * a.H + gy) * a.W + gx;
+    const int co = ct * 32 + ch * 8;
+    if (co < a.Cout) {
+      float v[8];
+      unpack<T>(*reinterpret_cast<const V16*>(stage + pw * ERS + ch * 8), v);
+      if (res) {
+        float r[8]; unpack<T>(*reinterpret_cast<const V16*>(res + pix * a.res_ld + co), r);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += r[e];
+      }
+      if (a.accumulate) {
+        float r[8]; unpack<T>(*reinterpret_cast<const V16*>(out + pix * a.out_ld + co), r);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += r[e];
+      }
+      if (a.relu) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+      }
+      *reinterpret_cast<V16*>(out + pix * a.out_ld + co) = pack<T>(v);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ conv3p: persistent variant for K <= 64 input channels
+// Layers with one or two 32-channel chunks (levels 0-1 forward, every data gradient whose K = Cout <= 64) are HBM-bound and
+// too short per tile to hide their own load -> MFMA -> store latency at one block per CU.  Here a block keeps ALL its weight
+// fragments in registers (NCH x taps x 2 fragments, loaded once), walks over many pixel tiles, and software-pipelines them:
+// the halo tile of tile t+1 is in flight (global -> registers) during the MFMAs of tile t and lands in the other LDS buffer
+// afterwards; the epilogue stores of tile t drain under the MFMAs of tile t+1.  One barrier per tile.
+template <typename T, int KS, int TH, int TW, int WM, int WN, int NCH>
+__global__ __launch_bounds__(64 * WM * WN) void conv3p_kernel(ConvArgs a) {
+  typedef MM<T> M;
+  constexpr int NT = 64 * WM * WN;
+  constexpr int BM = TH * TW;
+  constexpr int NTM = BM / (32 * WM);
+  constexpr int TAPS = KS * KS, PADP = KS / 2;
+  constexpr int IH = TH + 2 * PADP, IW = TW + 2 * PADP;
+  constexpr int KCP = KC + M::PAD;
+  constexpr int CV = KC / 8;
+  constexpr int NVI_TOT = IH * IW * CV, NVI = (NVI_TOT + NT - 1) / NT;
+  constexpr int CHB = IH * IW * KCP;                         // elements of one chunk's halo tile
+  constexpr int BUF = NCH * CHB;
+  constexpr int ERS = 40;
+  static_assert(sizeof(T) == 2, "conv3p layout");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  T* sIn = reinterpret_cast<T*>(smem_raw);                   // [2][NCH][IH*IW][KCP]
+  const int tid = threadIdx.x, l = tid & 63, wave = tid >> 6;
+  const int wm = wave % WM, wn = wave / WM;
+  T* stage = sIn + 2 * BUF + wave * (NTM * 32 * ERS);        // wave-private epilogue staging
+  const int tiles_x = a.W / TW, tiles_y = a.H / TH;
+  const int ntiles = tiles_x * tiles_y * a.B;
+  const int ct = blockIdx.y * WN + wn;
+  const bool have_w = ct * 32 < a.cout_pk;
+  const T* in = reinterpret_cast<const T*>(a.in);
+  const T* wbase = reinterpret_cast<const T*>(a.wpk) + (have_w ? ((size_t)ct * NCH) * TAPS * 2 * 512 : (size_t)0) + l * 8;
+
+  typename M::Frag fa[NCH][TAPS][2];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c)
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        union { V16 v; typename M::Frag f; } u;
+        u.v = *reinterpret_cast<const V16*>(wbase + ((size_t)(c * TAPS + t) * 2 + kk) * 512);
+        fa[c][t][kk] = u.f;
+      }
+  float bq[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+    bq[r] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
+  }
+  int pbase[NTM];
+#pragma unroll
+  for (int j = 0; j < NTM; ++j) {
+    const int m = (wm * NTM + j) * 32 + (l & 31);
+    pbase[j] = ((m / TW) * IW + (m % TW)) * KCP + 8 * (l >> 5);
+  }
+
+  V16 ri[NCH][NVI];
+  auto gload = [&](int tile) {
+    int pt = tile;
+    const int tx0 = (pt % tiles_x) * TW; pt /= tiles_x;
+    const int ty0 = (pt % tiles_y) * TH; pt /= tiles_y;
+    const int b = pt;
+#pragma unroll
+    for (int k = 0; k < NVI; ++k) {
+      const int i = tid + k * NT;
+      const int ii = i < NVI_TOT ? i : 0;
+      const int pix = ii / CV, cv = ii - pix * CV;
+      const int hy = pix / IW, hx = pix - hy * IW;
+      const int gy = ty0 + hy - PADP, gx = tx0 + hx - PADP;
+      const bool inimg = i < NVI_TOT && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+      const size_t off = inimg ? ((size_t)(b * a.H + gy) * a.W + gx) * a.in_ld + cv * 8 : (size_t)0;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const bool ok = inimg && c * KC + cv * 8 < a.Cin;
+        const V16 v = *reinterpret_cast<const V16*>(in + (ok ? off + c * KC : (size_t)0));
+        ri[c][k].w[0] = ok ? v.w[0] : 0u; ri[c][k].w[1] = ok ? v.w[1] : 0u; ri[c][k].w[2] = ok ? v.w[2] : 0u; ri[c][k].w[3] = ok ? v.w[3] : 0u;
+      }
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int k = 0; k < NVI; ++k) {
+      const int i = tid + k * NT;
+      if (i < NVI_TOT) {
+        const int pix = i / CV, cv = i - pix * CV;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) *reinterpret_cast<V16*>(sIn + buf * BUF + c * CHB + pix * KCP + cv * 8) = ri[c][k];
+      }
+    }
+  };
+
+  T* out = reinterpret_cast<T*>(a.out);
+  const T* res = reinterpret_cast<const T*>(a.res);
+  // XCD-aware walk: block b handles tiles b, b + G, ...; neighbouring blocks work on neighbouring tiles at the same time
+  int tile = blockIdx.x;
+  int cur = 0;
+  if (tile < ntiles) { gload(tile); lstore(0); }
+  __syncthreads();
+  for (; tile < ntiles; tile += gridDim.x) {
+    const int nxt = tile + gridDim.x;
+    if (nxt < ntiles) gload(nxt);
+    f32x16 acc[NTM];
+#pragma unroll
+    for (int j = 0; j < NTM; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = bq[r];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+      const T* sb = sIn + cur * BUF + c * CHB;
+#pragma unroll
+      for (int t = 0; t < TAPS; ++t) {
+        const int toff = ((t / KS) * IW + (t % KS)) * KCP;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          typename M::Frag fb[NTM];
+#pragma unroll
+          for (int j = 0; j < NTM; ++j) fb[j] = *reinterpret_cast<const typename M::Frag*>(sb + pbase[j] + toff + kk * 16);
+#pragma unroll
+          for (int j = 0; j < NTM; ++j) acc[j] = M::mfma(fa[c][t][kk], fb[j], acc[j]);
+        }
+      }
+    }
+    // ---- epilogue of this tile (wave-private staging, no block barrier needed)
+    {
+      int pt = tile;
+      const int tx0 = (pt % tiles_x) * TW; pt /= tiles_x;
+      const int ty0 = (pt % tiles_y) * TH; pt /= tiles_y;
+      const int b = pt;
+#pragma unroll
+      for (int j = 0; j < NTM; ++j) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float v[4] = {acc[j][4 * q], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]};
+          store4<T>(stage + (j * 32 + (l & 31)) * ERS + 8 * q + 4 * (l >> 5), v);
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < NTM * 2; ++it) {
+        const int i = it * 64 + l;
+        const int pw = i >> 2, ch = i & 3;
+        const int m = wm * NTM * 32 + pw;
+        const int gy = ty0 + m / TW, gx = tx0 + m % TW;
+        const size_t pix = (size_t)(b * a.H + gy) * a.W + gx;
+        const int co = ct * 32 + ch * 8;
+        if (co < a.Cout) {
+          float v[8];
+          unpack<T>(*reinterpret_cast<const V16*>(stage + pw * ERS + ch * 8), v);
+          if (res) {
+            float r[8]; unpack<T>(*reinterpret_cast<const V16*>(res + pix * a.res_ld + co), r);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += r[e];
+          }
+          if (a.accumulate) {
+            float r[8]; unpack<T>(*reinterpret_cast<const V16*>(out + pix * a.out_ld + co), r);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += r[e];
+          }
+          if (a.relu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+          }
+          *reinterpret_cast<V16*>(out + pix * a.out_ld + co) = pack<T>(v);
+        }
+      }
+    }
+    if (nxt < ntiles) lstore(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+}
+
+template <typename T, int KS, int TH, int TW, int WM, int WN, int NCH>
+static hipError_t launch_conv3p_cfg(const ConvArgs& a, hipStream_t s) {
+  constexpr int TAPS = KS * KS, PADP = KS / 2;
+  constexpr int IH = TH + 2 * PADP, IW = TW + 2 * PADP, KCP = KC + MM<T>::PAD, BN = 32 * WN;
+  constexpr size_t lds = ((size_t)2 * NCH * IH * IW * KCP + (size_t)(TH * TW / (32 * WM)) * 32 * 40 * WM * WN) * sizeof(T);
+  static_assert(lds <= 160 * 1024, "conv3p LDS");
+  auto kern = conv3p_kernel<T, KS, TH, TW, WM, WN, NCH>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_done = true;
+  }
+  const int ntiles = (a.W / TW) * (a.H / TH) * a.B;
+  const int gy = cdiv(a.Cout, BN);
+  const int per_cu = lds <= 76 * 1024 ? 2 : 1;                // resident blocks per CU by LDS
+  int gx = cdiv(256 * per_cu, gy);
+  if (gx > ntiles) gx = ntiles;
+  char tag[128];
+  const bool prof = prof_enabled();
+  if (prof) {
+    snprintf(tag, sizeof tag, "conv3p_kernel<%s,%d,%d,%d,%d,%d,%d>", ET<T>::DT == 1 ? "f16" : "bf16", KS, TH, TW, WM, WN, NCH);
+    const double px = (double)a.B * a.H * a.W;
+    prof_record(tag, 2.0 * px * a.Cout * (double)a.Cin * TAPS, px * (a.Cin + a.Cout) * sizeof(T) + (double)a.Cout * a.Cin * TAPS * sizeof(T), s, true);
+  }
+  hipLaunchKernelGGL(kern, dim3(gx, gy), dim3(64 * WM * WN), lds, s, a);
+  if (prof) prof_record(tag, 0, 0, s, false);
+  return hipGetLastError();
+}
+// persistent variant when the whole K fits one or two chunks; returns hipErrorNotSupported when no configuration applies
+template <typename T, int KS, int TH, int TW>
+static hipError_t launch_conv3p(const ConvArgs& a, hipStream_t s) {
+  const int nch = a.cin_pk / KC;
+  if (a.Cout > 64) {
+    if (nch == 1) return launch_conv3p_cfg<T, KS, TH, TW, 1, 4, 1>(a, s);
+    return hipErrorNotSupported;                              // 2 chunks + 80 KB staging exceed the LDS
+  }
+  if (a.Cout > 32) return nch == 1 ? launch_conv3p_cfg<T, KS, TH, TW, 2, 2, 1>(a, s) : launch_conv3p_cfg<T, KS, TH, TW, 2, 2, 2>(a, s);
+  return nch == 1 ? launch_conv3p_cfg<T, KS, TH, TW, 4, 1, 1>(a, s) : launch_conv3p_cfg<T, KS, TH, TW, 4, 1, 2>(a, s);
 }
 
 template <typename T, int KS, int TH, int TW, int WM, int WN>
@@ -431,7 +660,9 @@ static hipError_t launch_conv3_cfg(const ConvArgs& a, hipStream_t s) {
   constexpr int TAPS = KS * KS, PADP = KS / 2;
   constexpr int IH = TH + 2 * PADP, IW = TW + 2 * PADP, KCP = KC + MM<T>::PAD, BN = 32 * WN;
   (void)TAPS;
-  constexpr size_t lds = (size_t)2 * IH * IW * KCP * sizeof(T);
+  constexpr size_t lds_in = (size_t)2 * IH * IW * KCP * sizeof(T);
+  constexpr size_t lds_ep = (size_t)(TH * TW / (32 * WM)) * 32 * 40 * WM * WN * sizeof(T);      // epilogue staging, wave-private
+  constexpr size_t lds = lds_in > lds_ep ? lds_in : lds_ep;
   auto kern = conv3_kernel<T, KS, TH, TW, WM, WN>;
   static bool attr_done = false;
   if (!attr_done) {
@@ -454,6 +685,12 @@ static hipError_t launch_conv3_cfg(const ConvArgs& a, hipStream_t s) {
 template <typename T, int KS>
 static hipError_t launch_conv3(const ConvArgs& a, hipStream_t s) {
   if constexpr (sizeof(T) == 2) {
+    if (a.cin_pk <= 2 * KC && !getenv("PU_NO_CONV3P")) {       // short-K layers: persistent, weight-resident variant
+      hipError_t e = hipErrorNotSupported;
+      if (a.W % 32 == 0 && a.H % 8 == 0) e = launch_conv3p<T, KS, 8, 32>(a, s);
+      else if (a.W % 16 == 0 && a.H % 16 == 0) e = launch_conv3p<T, KS, 16, 16>(a, s);
+      if (e != hipErrorNotSupported) return e;
+    }
     if (a.W % 32 == 0 && a.H % 8 == 0) {
       if (a.Cout > 64) return launch_conv3_cfg<T, KS, 8, 32, 1, 4>(a, s);
       if (a.Cout > 32) return launch_conv3_cfg<T, KS, 8, 32, 2, 2>(a, s);
