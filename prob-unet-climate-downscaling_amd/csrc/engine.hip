@@ -873,11 +873,13 @@ int pu_elbo_fwd_bwd(pu_ctx* c, const float* x, const float* target, const float*
     int q;
     CKH(launch_nchw_to_nhwc<T>(x, (long)ci * HW, ci, nullptr, 0, with_b(c->x_in.v, B), s));
     CKH(launch_nchw_to_nhwc<T>(x, (long)ci * HW, ci, target, Co, with_b(c->xy_in.v, B), s));
+    // host enqueue order matters (~5 us per launch): the critical-path U-Net goes first, the latent encoders are enqueued on
+    // the second side stream afterwards and still finish long before the U-Net does
     hipStream_t s2;
     if ((q = fork2(c, s, &s2))) return q;
+    if ((q = unet_forward<T>(c, B, train, seed, s))) return q;
     if ((q = gauss_forward<T>(c, c->prior, B, s2))) return q;
     if ((q = gauss_forward<T>(c, c->post, B, s2))) return q;
-    if ((q = unet_forward<T>(c, B, train, seed, s))) return q;
     if ((q = join2(c, s, s2))) return q;
     CKH(hipMemsetAsync(c->scal, 0, PU_NUM_SCALARS * sizeof(float), s));
     LatentArgs la; memset(&la, 0, sizeof la);
@@ -904,9 +906,9 @@ int pu_elbo_fwd_bwd(pu_ctx* c, const float* x, const float* target, const float*
     lb.dmu_q = c->post.dmu; lb.dls_q = c->post.dls; lb.dmu_p = c->prior.dmu; lb.dls_p = c->prior.dls;
     CKH(launch_latent_bwd(lb, s));
     if ((q = fork2(c, s, &s2))) return q;
+    if ((q = unet_backward<T>(c, s))) return q;
     if ((q = gauss_backward<T>(c, c->post, s2))) return q;
     if ((q = gauss_backward<T>(c, c->prior, s2))) return q;
-    if ((q = unet_backward<T>(c, s))) return q;
     if ((q = join2(c, s, s2))) return q;
     return join_side(c, s);
   });

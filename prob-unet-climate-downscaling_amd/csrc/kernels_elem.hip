@@ -162,6 +162,7 @@ __global__ void gn_apply_kernel(GNArgs a) {
   const T* xp = reinterpret_cast<const T*>(a.x.p);
   T* yp = reinterpret_cast<T*>(a.y.p);
   const float keep = 1.f - a.drop_p, inv_keep = a.drop_p > 0.f ? 1.f / keep : 1.f;
+  const uint32_t dkey = drop_key(a.drop_seed, a.drop_stream), dthr = drop_thr16(keep);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int cv = (int)(i % CV);
     long p = i / CV;
@@ -191,7 +192,11 @@ __global__ void gn_apply_kernel(GNArgs a) {
       if (RS == RS_NONE && a.drop_p > 0.f) {
         const uint64_t base = (((uint64_t)b * OH + oy) * OW + ox) * (uint64_t)C + (uint64_t)cv * VEC;
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) o[e] = hash_uniform(a.drop_seed, a.drop_stream, base + e) < keep ? o[e] * inv_keep : 0.f;
+        for (int e = 0; e < VEC; e += 2) {
+          const uint32_t r = drop_pair(dkey, base + e);
+          o[e] = (r & 0xffffu) < dthr ? o[e] * inv_keep : 0.f;
+          o[e + 1] = (r >> 16) < dthr ? o[e + 1] * inv_keep : 0.f;
+        }
       }
     }
     stv<T>(yp + (((long)b * OH + oy) * OW + ox) * a.y.ld + cv * VEC, pack<T>(o));
@@ -243,15 +248,18 @@ __device__ __forceinline__ void gn_dv(const GNArgs& f, const TV& dy, int b, int 
       for (int e = 0; e < VEC; ++e) dh[e] += t[e];
     }
   }
+  if (RS == RS_NONE && f.drop_p > 0.f) {
+    const uint32_t dkey = drop_key(f.drop_seed, f.drop_stream), dthr = drop_thr16(keep);
+    const uint64_t base = ((uint64_t)b * HW + p) * (uint64_t)C + (uint64_t)(cv * VEC);
 #pragma unroll
-  for (int e = 0; e < VEC; ++e) {
-    float d = dh[e];
-    if (RS == RS_NONE && f.drop_p > 0.f) {
-      const uint64_t idx = ((uint64_t)b * HW + p) * (uint64_t)C + (uint64_t)(cv * VEC + e);
-      d = hash_uniform(f.drop_seed, f.drop_stream, idx) < keep ? d * inv_keep : 0.f;
+    for (int e = 0; e < VEC; e += 2) {
+      const uint32_t r = drop_pair(dkey, base + e);
+      dh[e] = (r & 0xffffu) < dthr ? dh[e] * inv_keep : 0.f;
+      dh[e + 1] = (r >> 16) < dthr ? dh[e + 1] * inv_keep : 0.f;
     }
-    dv[e] = d * dsilu_f(A[e] * xv[e] + Bc[e]);
   }
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) dv[e] = dh[e] * dsilu_f(A[e] * xv[e] + Bc[e]);
 }
 
 template <typename T, int RS>

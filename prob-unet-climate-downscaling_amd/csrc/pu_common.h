@@ -86,16 +86,24 @@ struct TV {
   __host__ __device__ size_t pixels() const { return (size_t)B * H * W; }
 };
 
-__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
-__device__ __forceinline__ float dsilu_f(float v) { float s = 1.0f / (1.0f + __expf(-v)); return s * (1.0f + v * (1.0f - s)); }
+// SiLU and its derivative with the hardware reciprocal (v_rcp_f32, 1 ulp) instead of an IEEE division
+__device__ __forceinline__ float sigmoid_f(float v) { return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+__device__ __forceinline__ float silu_f(float v) { return v * sigmoid_f(v); }
+__device__ __forceinline__ float dsilu_f(float v) { const float s = sigmoid_f(v); return s * (1.0f + v * (1.0f - s)); }
 
-// counter-hash RNG for dropout: uniform in [0,1) from (seed, stream id, element index). Regenerated in backward.
-__device__ __forceinline__ float hash_uniform(uint64_t seed, uint32_t stream, uint64_t idx) {
-  uint64_t z = seed + 0x9E3779B97F4A7C15ull * (idx + 1) + ((uint64_t)stream << 40);
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z = z ^ (z >> 31);
-  return (float)(z >> 40) * (1.0f / 16777216.0f);
+// Counter-hash RNG for dropout, regenerated (never stored) in backward.  One 32-bit hash serves TWO consecutive elements
+// (16 bits each): keep iff u16 < thr16 = round(keep * 65536).  key = drop_key(seed, stream) is computed once per kernel.
+__device__ __forceinline__ uint32_t hash32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+__device__ __forceinline__ uint32_t drop_key(uint64_t seed, uint32_t stream) {
+  return hash32((uint32_t)seed ^ hash32((uint32_t)(seed >> 32) + 0x9E3779B9u * (stream + 1u)));
+}
+__device__ __forceinline__ uint32_t drop_thr16(float keep) { return (uint32_t)(keep * 65536.0f + 0.5f); }
+// 16-bit uniforms of the element pair containing element index `idx` (idx even): low half -> idx, high half -> idx + 1
+__device__ __forceinline__ uint32_t drop_pair(uint32_t key, uint64_t idx) {
+  return hash32((uint32_t)(idx >> 1) * 0x9E3779B1u + key + (uint32_t)(idx >> 33));
 }
 
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -420,11 +420,12 @@ class ProbabilisticUNet(nn.Module):
         if g is not None:
             eg = eg * g.reshape(())
         P = self._params_in(lo, hi)
-        fresh = all(p.grad is None for p, _, _ in P)
-        if fresh:
+        views = self._grad_views(lo, hi)
+        fresh = all(p.grad is None for p, _, _ in P[:4]) and P[-1][0].grad is None and P[len(P) // 2][0].grad is None
+        if fresh and all(p.grad is None for p, _, _ in P):
             self._flat_grad[lo:hi].copy_(eg)
-            for p, off, n in P:
-                p.grad = self._flat_grad[off:off + n].view(p.shape)
+            for (p, off, n), v in zip(P, views):
+                p.grad = v
         else:
             for p, off, n in P:
                 ge = eg[off - lo:off - lo + n].view(p.shape)
@@ -432,6 +433,13 @@ class ProbabilisticUNet(nn.Module):
                     p.grad = ge.clone()
                 else:
                     p.grad.add_(ge)
+
+    def _grad_views(self, lo, hi):
+        key = ("gv", lo, hi, self._flat_grad.data_ptr())
+        cache = self.__dict__.setdefault("_pin_cache", {})
+        if key not in cache:
+            cache[key] = [self._flat_grad[off:off + n].view(p.shape) for p, off, n in self._params_in(lo, hi)]
+        return cache[key]
 
     def _params_in(self, lo, hi):
         key = (lo, hi)
