@@ -160,6 +160,7 @@ def main():
     ap.add_argument("--members", type=int, default=CFG3["M"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optimizer", action="store_true", help="time ELBO fwd+bwd only (diagnostic; not the reported metric)")
+    ap.add_argument("--flat-adamw", action="store_true", help="use the fused flat AdamW (pu_adamw_step) instead of torch.optim.AdamW")
     ap.add_argument("--mode", default="train", choices=["train", "sample"],
                     help="sample = BASELINE config 5: prior samples/s, 64 samples per lo-res input (U-Net + prior once, 64 x Fcomb)")
     ap.add_argument("--samples", type=int, default=64)
@@ -187,10 +188,14 @@ def main():
     torch.manual_seed(1234 + rank)                   # rank-offset reparameterisation noise (dropout seeds are rank-offset inside the model)
     if world > 1:
         model.enable_data_parallel()
-    try:
-        opt = torch.optim.AdamW(model.parameters(), lr=1e-4, fused=True)     # same optimizer as main.py:103, fused multi-tensor kernel
-    except Exception:
-        opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
+    if args.flat_adamw:
+        import probunet_amd as pa
+        opt = pa.FlatAdamW(model, lr=1e-4)
+    else:
+        try:
+            opt = torch.optim.AdamW(model.parameters(), lr=1e-4, fused=True)     # same optimizer as main.py:103, fused multi-tensor kernel
+        except Exception:
+            opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
     x, y = synthetic_fields(cfg["batch"], cfg["input_channels"], cfg["num_classes"], cfg["H"], cfg["W"], 1234 + rank, device)
     t_stamp = torch.zeros(cfg["batch"], 1, device=device)
 
@@ -257,7 +262,7 @@ def main():
                scaling="weak", vs_baseline=None, dtype=args.dtype, data="synthetic",
                config=dict(workload=f"cfg3: 4->1 planes, 256x256, latent 12, depth-5 U-Net, {cfg['batch']} field pairs per GPU, "
                                     f"afCRPS-ELBO M={cfg['M']} fwd+bwd, train mode (dropout 0.1)"
-                                    + ("" if args.no_optimizer else " + AdamW step") + (" + RCCL grad all-reduce" if world > 1 else ""),
+                                    + ("" if args.no_optimizer else (" + fused flat AdamW step" if args.flat_adamw else " + AdamW step")) + (" + RCCL grad all-reduce" if world > 1 else ""),
                            global_batch=world * cfg["batch"], parallelism=f"dp{world}",
                            elbo_fwd_bwd_tflop_per_step=round(3 * fwd_flops / 1e12, 3),
                            model_tflops=round(3 * fwd_flops * world / (elapsed / args.steps) / 1e12, 2), final_loss=loss_val),

@@ -120,6 +120,11 @@ int pu_elbo_fwd_bwd(pu_ctx*, const float* x, const float* target, const float* e
 int pu_sample(pu_ctx*, const float* x, const float* target_or_null, const float* eps, int B, int n,
               float* out, float* mu, float* sigma, void* stream);
 
+/* ---- optimizer (replaces torch.optim.AdamW(model.parameters(), lr=1e-4).step(), main.py:103, train_prob_unet_model.py:141) on
+ *      the flat buffers: one fused pass; exp_avg / exp_avg_sq are caller-owned fp32 arrays of n elements; step counts from 1. */
+int pu_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int64_t step, void* stream);
+
 /* ---- introspection for bench/roofline ------------------------------------------------------------------ */
 int64_t pu_workspace_bytes(pu_ctx*);
 /* conv + matmul FLOPs (2*MAC) of one ELBO forward for batch B, members M (BASELINE.md §2 counting). */

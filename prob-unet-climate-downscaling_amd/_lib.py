@@ -71,6 +71,8 @@ def lib():
     L.pu_sample.restype = i32; L.pu_sample.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp]
     L.pu_elbo_fwd_flops.restype = C.c_double; L.pu_elbo_fwd_flops.argtypes = [vp, i32, i32]
     L.pu_profile_enable.restype = i32; L.pu_profile_enable.argtypes = [i32]
+    L.pu_adamw_step.restype = i32
+    L.pu_adamw_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i64, vp]
     L.pu_set_overlap.restype = i32; L.pu_set_overlap.argtypes = [vp, i32]
     L.pu_profile_collect.restype = i32; L.pu_profile_collect.argtypes = [C.POINTER(PuProfEntry), i32]
     L.pu_op_conv.restype = i32

@@ -697,6 +697,14 @@ int pu_param_table(pu_ctx* c, const pu_param_desc** out, int* n) {
 }
 int64_t pu_param_count(pu_ctx* c) { return c ? c->nparams : -1; }
 int pu_profile_enable(int on) { prof_enable(on != 0); return PU_OK; }
+int pu_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, int64_t step, void* stream) {
+  if (!params || !grads || !exp_avg || !exp_avg_sq || n < 0 || step < 1) return PU_ERR_INVALID;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  const hipError_t e = launch_adamw_flat(params, grads, exp_avg, exp_avg_sq, (long)n, lr, beta1, beta2, eps, weight_decay,
+                                         (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), (hipStream_t)stream);
+  return e == hipSuccess ? PU_OK : PU_ERR_HIP;
+}
 int pu_set_overlap(pu_ctx* c, int on) {
   if (!c) return PU_ERR_INVALID;
   c->use_side = on != 0 && c->side && c->side2 && c->dt != PU_F32 && !getenv("PU_NO_SIDE_STREAM");

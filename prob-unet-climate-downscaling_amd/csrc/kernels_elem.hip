@@ -836,6 +836,39 @@ hipError_t launch_fill(float* p, float v, long n, hipStream_t s) {
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------ flat AdamW (torch.optim.AdamW semantics, main.py:103)
+// One pass over the flat fp32 buffers (parameters, gradients, exp_avg, exp_avg_sq): 4 reads + 3 writes per element.
+__global__ void adamw_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
+                                  float lr, float beta1, float beta2, float eps, float wd, float step_size, float inv_bc2_sqrt) {
+  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long)gridDim.x * blockDim.x * 4) {
+    if (i + 4 <= n) {
+      f32x4 pp = *reinterpret_cast<f32x4*>(p + i), gg = *reinterpret_cast<const f32x4*>(g + i);
+      f32x4 mm = *reinterpret_cast<f32x4*>(m + i), vv = *reinterpret_cast<f32x4*>(v + i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        pp[e] *= 1.f - lr * wd;
+        mm[e] = mm[e] + (gg[e] - mm[e]) * (1.f - beta1);
+        vv[e] = vv[e] * beta2 + gg[e] * gg[e] * (1.f - beta2);
+        pp[e] -= step_size * mm[e] / (sqrtf(vv[e]) * inv_bc2_sqrt + eps);
+      }
+      *reinterpret_cast<f32x4*>(p + i) = pp; *reinterpret_cast<f32x4*>(m + i) = mm; *reinterpret_cast<f32x4*>(v + i) = vv;
+    } else {
+      for (long k = i; k < n; ++k) {
+        float pk = p[k] * (1.f - lr * wd);
+        const float mk = m[k] + (g[k] - m[k]) * (1.f - beta1);
+        const float vk = v[k] * beta2 + g[k] * g[k] * (1.f - beta2);
+        pk -= step_size * mk / (sqrtf(vk) * inv_bc2_sqrt + eps);
+        p[k] = pk; m[k] = mk; v[k] = vk;
+      }
+    }
+  }
+}
+hipError_t launch_adamw_flat(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps, float wd,
+                             float step_size, float inv_bc2_sqrt, hipStream_t s) {
+  hipLaunchKernelGGL(adamw_flat_kernel, dim3(ew_grid((n + 3) / 4)), dim3(256), 0, s, p, g, m, v, n, lr, beta1, beta2, eps, wd, step_size, inv_bc2_sqrt);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ explicit instantiations
 #define PU_INST(T)                                                                                                   \
   template hipError_t launch_nchw_to_nhwc<T>(const float*, long, int, const float*, int, TV, hipStream_t);           \

@@ -131,6 +131,8 @@ struct FcombBwdArgs {
 template <typename T> hipError_t launch_fcomb_bwd(const FcombBwdArgs&, hipStream_t);
 
 hipError_t launch_fill(float* p, float v, long n, hipStream_t);
+hipError_t launch_adamw_flat(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps, float wd,
+                             float step_size, float inv_bc2_sqrt, hipStream_t);
 
 // ---------------------------------------------------------------- optional per-kernel-class profiling (bench roofline)
 // When enabled, every MFMA conv launch is bracketed by HIP events on its own stream; prof_collect() sums elapsed time,

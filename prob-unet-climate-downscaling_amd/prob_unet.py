@@ -722,3 +722,40 @@ def _param_table_host(m: ProbabilisticUNet):
     add("fcomb.layers.2.weight", (f0, f0, 1, 1)); add("fcomb.layers.2.bias", (f0,))
     add("fcomb.layers.4.weight", (m.num_classes, f0, 1, 1)); add("fcomb.layers.4.bias", (m.num_classes,))
     return out
+
+
+class FlatAdamW:
+    """torch.optim.AdamW(model.parameters(), lr=1e-4) of the reference trainer (main.py:103) as ONE fused HIP pass over the
+    engine's flat parameter / gradient buffers (pu_adamw_step).  Same update rule and defaults as torch (betas 0.9/0.999,
+    eps 1e-8, weight_decay 0.01; dead parameters with zero gradient still decay).  Use: opt = FlatAdamW(model, lr=1e-4);
+    loss.backward(); opt.step(); opt.zero_grad()."""
+
+    def __init__(self, model: ProbabilisticUNet, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        self.model, self.lr, self.betas, self.eps, self.weight_decay = model, lr, betas, eps, weight_decay
+        self.step_count = 0
+        self.exp_avg = None
+        self.exp_avg_sq = None
+
+    def zero_grad(self, set_to_none: bool = True):
+        for p in self.model.parameters():
+            p.grad = None
+
+    @torch.no_grad()
+    def step(self):
+        m = self.model
+        if m._flat is None:
+            raise L.ProbUNetLibraryError("FlatAdamW.step() before the first forward: the flat buffers do not exist yet")
+        m._check_views()
+        if self.exp_avg is None or self.exp_avg.device != m._flat.device:
+            self.exp_avg = torch.zeros_like(m._flat); self.exp_avg_sq = torch.zeros_like(m._flat)
+        g0 = next(iter(m.parameters())).grad
+        if g0 is None:
+            return
+        if g0.data_ptr() != m._flat_grad.data_ptr():             # gradients were accumulated outside the flat buffer
+            for p, off, n in m._params_in(0, m._nparams):
+                m._flat_grad[off:off + n].copy_((p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1))
+        self.step_count += 1
+        L.check(L.lib().pu_adamw_step(L.ptr(m._flat), L.ptr(m._flat_grad), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq), m._nparams,
+                                      float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
+                                      float(self.weight_decay), self.step_count, L.current_stream()), m._ctx, "pu_adamw_step")
+        m._params_dirty()

@@ -277,3 +277,26 @@ def test_bf16_engine_and_posterior_sampling():
         assert_close(out[:, 7].cpu(), m.fcomb(feat, z).cpu(), rtol=5e-2, atol=5e-2, what="sample vs sub-modules")
     with pytest.raises(pa._lib.ProbUNetLibraryError):
         m.train(); m.elbo(x, y, None, M=17)                    # fused afCRPS kernel supports M <= 16
+
+
+@pytest.mark.parametrize("name", ["tiny22"])
+def test_flat_adamw_matches_reference_step(name):
+    """pu_adamw_step on the flat buffers == torch.optim.AdamW(lr=1e-4) of the reference trainer (golden after_adamw), two steps
+    cross-checked against torch's own AdamW on a twin model."""
+    meta, g = load_golden(name)
+    x, y, eps = t(g["x"]).to(DEV), t(g["y"]).to(DEV), t(g["eps"]).to(DEV)
+    m = build(meta).train(); m.dropout = 0.0
+    opt = pa.FlatAdamW(m, lr=1e-4)
+    twin = build(meta).train(); twin.dropout = 0.0
+    topt = torch.optim.AdamW(twin.parameters(), lr=1e-4)
+    for it in range(2):
+        for mod, o in ((m, opt), (twin, topt)):
+            loss, _, _ = mod.elbo(x, y, None, M=eps.shape[0], eps=eps)
+            o.zero_grad(); loss.backward(); o.step()
+        if it == 0:
+            sd = m.state_dict()
+            for k, cs in meta["after_adamw"].items():
+                mine = checksum(sd[k])
+                assert abs(mine["sum"] - cs["sum"]) <= 1e-5 * max(1.0, cs["abssum"]), k
+    a = torch.cat([p.detach().flatten() for p in m.parameters()]); b = torch.cat([p.detach().flatten() for p in twin.parameters()])
+    assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(b.abs().max()))
