@@ -57,6 +57,7 @@ struct GNArgs {
   float drop_p; uint64_t drop_seed; uint32_t drop_stream;   // drop_p == 0 -> no dropout
   // workspaces (fp32): part [B][nchunk][C][2], stat [B][G][2] (mean, rstd), coef [B][C][2] (A, Bc)
   float* part; float* stat; float* coef; int nchunk;
+  int b0;                     // batch offset of this launch inside the tensor (batch-chunked launches; keeps the dropout index global)
 };
 template <typename T> hipError_t launch_gn_fwd(const GNArgs&, hipStream_t);
 struct GNBwdArgs {
