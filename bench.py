@@ -233,13 +233,15 @@ def main():
     lib = L.lib()
     roofline = None
     fwd_flops = model.elbo_fwd_flops(cfg["batch"], cfg["M"])
+    # every rank runs the same two extra steps (they contain the gradient all-reduce); only rank 0 records events
+    lib.pu_set_overlap(model._ctx, 0)                # serial kernels: durations not inflated by co-running side-stream kernels
+    step(); torch.cuda.synchronize()
     if rank == 0:
-        lib.pu_set_overlap(model._ctx, 0)            # serial kernels: durations not inflated by co-running side-stream kernels
-        step(); torch.cuda.synchronize()
         lib.pu_profile_enable(1)
-        step(); torch.cuda.synchronize()
-        lib.pu_profile_enable(0)
-        lib.pu_set_overlap(model._ctx, 1)
+    step(); torch.cuda.synchronize()
+    lib.pu_profile_enable(0)
+    lib.pu_set_overlap(model._ctx, 1)
+    if rank == 0:
         ents = (L.PuProfEntry * 64)()
         n = lib.pu_profile_collect(ents, 64)
         rows = [dict(name=ents[i].name.decode(), launches=ents[i].launches, ms=ents[i].ms, flops=ents[i].flops, bytes=ents[i].bytes) for i in range(n)]
