@@ -371,18 +371,26 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3_kernel(ConvArgs a) {
     const int cn = more ? c + 1 : c;               // the last chunk harmlessly re-reads its own fragments
     if (more) gload((c + 1) * KC);
     const T* sb = sIn + cur * BUF;
+    // software-pipelined over the 2*TAPS (tap, k-step) groups: the NTM LDS fragment reads of group g+1 are issued between
+    // the MFMAs of group g (one ds_read_b128 per MFMA slot), so no MFMA waits on a read issued right before it
+    typename M::Frag fb[2][NTM];
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t) {
-      const int toff = ((t / KS) * IW + (t % KS)) * KCP;
+    for (int j = 0; j < NTM; ++j) fb[0][j] = *reinterpret_cast<const typename M::Frag*>(sb + pbase[j]);
 #pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        typename M::Frag fb[NTM];
+    for (int g = 0; g < 2 * TAPS; ++g) {
+      const int t = g >> 1, kk = g & 1;
+      if (g + 1 < 2 * TAPS) {
+        const int t1 = (g + 1) >> 1, kk1 = (g + 1) & 1;
+        const int toff1 = ((t1 / KS) * IW + (t1 % KS)) * KCP + kk1 * 16;
 #pragma unroll
-        for (int j = 0; j < NTM; ++j) fb[j] = *reinterpret_cast<const typename M::Frag*>(sb + pbase[j] + toff + kk * 16);
-#pragma unroll
-        for (int j = 0; j < NTM; ++j) acc[j] = M::mfma(fa[t][kk], fb[j], acc[j]);
-        fa[t][kk] = wload(cn, t, kk);
+        for (int j = 0; j < NTM; ++j) fb[(g + 1) & 1][j] = *reinterpret_cast<const typename M::Frag*>(sb + pbase[j] + toff1);
       }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < NTM; ++j) acc[j] = M::mfma(fa[t][kk], fb[g & 1][j], acc[j]);
+      fa[t][kk] = wload(cn, t, kk);
+      __builtin_amdgcn_sched_barrier(0);           // keep [reads of g+1 | MFMAs of g | weight refill] as issued: the reads land
+                                                   // under the 8 MFMAs instead of being sunk next to their consumers
     }
     if (more) lstore(cur ^ 1);
     __syncthreads();
@@ -691,6 +699,9 @@ static hipError_t launch_conv3(const ConvArgs& a, hipStream_t s) {
       else if (a.W % 16 == 0 && a.H % 16 == 0) e = launch_conv3p<T, KS, 16, 16>(a, s);
       if (e != hipErrorNotSupported) return e;
     }
+    // 128-pixel tiles for the wide-cout configuration: ~200 registers -> two co-resident blocks per CU hide each other's
+    // prologue / epilogue / barrier stalls (256 -> 256 @32x32: 39.5 -> 35.8 us, 128 -> 128 @64x64: 48 -> 39 us)
+    if (a.W % 32 == 0 && a.H % 4 == 0 && a.Cout > 64) return launch_conv3_cfg<T, KS, 4, 32, 1, 4>(a, s);
     if (a.W % 32 == 0 && a.H % 8 == 0) {
       if (a.Cout > 64) return launch_conv3_cfg<T, KS, 8, 32, 1, 4>(a, s);
       if (a.Cout > 32) return launch_conv3_cfg<T, KS, 8, 32, 2, 2>(a, s);

@@ -371,25 +371,14 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(GNBwdArgs a) {
     o[0] = rstd * gp;
     o[1] = -rstd * rstd * m2;
     o[2] = -rstd * m1 + rstd * rstd * m2 * mean;
-    // keep per-(b,c) sums for the parameter-gradient kernel in chunk slot 0
-    float* keepp = a.part2 + (((long)b * f.nchunk) * C + c) * 2;
-    keepp[0] = cs[c * 2]; keepp[1] = cs[c * 2 + 1];
+    // parameter gradients: this sample's contribution (fp32 atomics over the B samples; ADDED into the flat gradient)
+    const float S1 = cs[c * 2] * a.inv_scale, S2 = cs[c * 2 + 1] * a.inv_scale;
+    const float sc = f.scale ? f.scale[c] : 0.f;
+    atomicAdd(a.dgamma + c, (1.f + sc) * S2);
+    atomicAdd(a.dbeta + c, (1.f + sc) * S1);
+    if (a.dscale) atomicAdd(a.dscale + c, f.gamma[c] * S2 + f.beta[c] * S1);
+    if (a.dshift) atomicAdd(a.dshift + c, S1);
   }
-}
-
-__global__ void gn_param_grad_kernel(GNBwdArgs a) {
-  const GNArgs& f = a.f;
-  const int C = f.x.C;
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float S1 = 0.f, S2 = 0.f;
-  for (int b = 0; b < f.x.B; ++b) { const float* pp = a.part2 + (((long)b * f.nchunk) * C + c) * 2; S1 += pp[0]; S2 += pp[1]; }
-  const float s = f.scale ? f.scale[c] : 0.f;
-  S1 *= a.inv_scale; S2 *= a.inv_scale;
-  a.dgamma[c] += (1.f + s) * S2;
-  a.dbeta[c] += (1.f + s) * S1;
-  if (a.dscale) a.dscale[c] += f.gamma[c] * S2 + f.beta[c] * S1;
-  if (a.dshift) a.dshift[c] += S1;
 }
 
 template <typename T, int RS>
@@ -445,7 +434,6 @@ hipError_t launch_gn_bwd(const GNBwdArgs& a0, hipStream_t s) {
     else if (f.resample == RS_DOWN) hipLaunchKernelGGL((gn_bwd_pass2_kernel<T, RS_DOWN>), dim3(ew_grid(total)), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((gn_bwd_pass2_kernel<T, RS_UP>), dim3(ew_grid(total)), dim3(256), 0, s, a);
   }
-  hipLaunchKernelGGL(gn_param_grad_kernel, dim3(cdiv(a0.f.x.C, 256)), dim3(256), 0, s, a0);      // sums over the whole batch
   return hipGetLastError();
 }
 

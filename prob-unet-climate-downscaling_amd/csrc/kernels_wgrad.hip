@@ -44,27 +44,31 @@ __device__ __forceinline__ Frag tr_frag(const uint16_t* p0, const uint16_t* p1) 
 
 constexpr int WBCO = 64;
 
-template <typename T, int KS, int TH, int TW, int BCI>
-__global__ __launch_bounds__(256) void conv_wgrad16_kernel(WgradArgs a) {
+template <typename T, int KS, int TH, int TW, int BCI, int NW>
+__global__ __launch_bounds__(64 * NW) void conv_wgrad16_kernel(WgradArgs a) {
   typedef MMW<T> M;
+  constexpr int NTH = 64 * NW;
   constexpr int TAPS = KS * KS, PADP = KS / 2;
   constexpr int BM = TH * TW;
   constexpr int IH = TH + 2 * PADP, IW = TW + 2 * PADP, NPH = IH * IW;
   constexpr int CIS = BCI / 32;                       // cin sub-tiles
   constexpr int BUF = (2 * BM + CIS * NPH) * 32;      // elements per LDS buffer
-  constexpr int NVD = BM * 8 / 256;                   // 16-byte vectors of the dy tile per thread
+  constexpr int NVD_TOT = BM * 8, NVD = (NVD_TOT + NTH - 1) / NTH;   // 16-byte vectors of the dy tile per thread
   constexpr int NVA_TOT = NPH * (BCI / 8);
-  constexpr int NVA = (NVA_TOT + 255) / 256;
-  // wave roles: BCI == 64: (cout sub-tile, cin sub-tile) x all taps;  BCI == 32: (cout sub-tile, tap half)
-  constexpr int NJ = BCI == 64 ? TAPS : (TAPS + 1) / 2;
+  constexpr int NVA = (NVA_TOT + NTH - 1) / NTH;
+  // wave roles: 4 waves, BCI == 64: (cout sub-tile, cin sub-tile) x all taps;  4 waves, BCI == 32: (cout sub-tile, tap half);
+  //             8 waves, BCI == 64: (cout sub-tile, cin sub-tile, tap half) - two waves per SIMD hide each other's LDS waits
+  constexpr bool SPLIT_TAPS = (BCI == 32) || (NW == 8);
+  constexpr int NJ = SPLIT_TAPS ? (TAPS + 1) / 2 : TAPS;
+  static_assert((NW == 4) || (NW == 8 && BCI == 64), "wave roles");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   uint16_t* lds = reinterpret_cast<uint16_t*>(smem_raw);
 
   const int tid = threadIdx.x, l = tid & 63, wave = tid >> 6;
   const int ct = wave & 1;
-  const int it = BCI == 64 ? (wave >> 1) : 0;
-  const int tap0 = BCI == 64 ? 0 : (wave >> 1) * NJ;
+  const int it = BCI == 64 ? ((wave >> 1) & 1) : 0;
+  const int tap0 = !SPLIT_TAPS ? 0 : (BCI == 64 ? (wave >> 2) : (wave >> 1)) * NJ;
   const int co0 = blockIdx.y * WBCO, ci0 = blockIdx.z * BCI;
   const int tiles_x = a.W / TW, tiles_y = a.H / TH;
   const int ntiles = tiles_x * tiles_y * a.B;
@@ -85,16 +89,16 @@ __global__ __launch_bounds__(256) void conv_wgrad16_kernel(WgradArgs a) {
     const int b = pt;
 #pragma unroll
     for (int k = 0; k < NVD; ++k) {
-      const int i = tid + k * 256;
-      const int pix = i >> 3, cv = i & 7;
+      const int i = tid + k * NTH;
+      const int pix = (i >> 3) % BM, cv = i & 7;
       const int gy = ty0 + pix / TW, gx = tx0 + pix % TW;
       const int co = co0 + cv * 8;
       rd[k] = zero16();
-      if (co < a.Cout) rd[k] = *reinterpret_cast<const V16*>(dy + ((size_t)(b * a.H + gy) * a.W + gx) * a.dy_ld + co);
+      if (i < NVD_TOT && co < a.Cout) rd[k] = *reinterpret_cast<const V16*>(dy + ((size_t)(b * a.H + gy) * a.W + gx) * a.dy_ld + co);
     }
 #pragma unroll
     for (int k = 0; k < NVA; ++k) {
-      const int i = tid + k * 256;
+      const int i = tid + k * NTH;
       ra[k] = zero16();
       if (i < NVA_TOT) {
         const int hp = i / (BCI / 8), cv = i % (BCI / 8);
@@ -110,13 +114,13 @@ __global__ __launch_bounds__(256) void conv_wgrad16_kernel(WgradArgs a) {
     uint16_t* sA = sDy + 2 * BM * 32;
 #pragma unroll
     for (int k = 0; k < NVD; ++k) {
-      const int i = tid + k * 256;
+      const int i = tid + k * NTH;
       const int pix = i >> 3, cv = i & 7;
-      *reinterpret_cast<V16*>(sDy + ((cv >> 2) * BM + pix) * 32 + (cv & 3) * 8) = rd[k];
+      if (i < NVD_TOT) *reinterpret_cast<V16*>(sDy + ((cv >> 2) * BM + pix) * 32 + (cv & 3) * 8) = rd[k];
     }
 #pragma unroll
     for (int k = 0; k < NVA; ++k) {
-      const int i = tid + k * 256;
+      const int i = tid + k * NTH;
       if (i < NVA_TOT) {
         const int hp = i / (BCI / 8), cv = i % (BCI / 8);
         *reinterpret_cast<V16*>(sA + ((cv >> 2) * NPH + hp) * 32 + (cv & 3) * 8) = ra[k];
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(256) void conv_wgrad16_kernel(WgradArgs a) {
     if (do_bias) {
       const uint16_t* col = lds + cur * BUF + (((tid & 63) >> 5) * BM) * 32 + (tid & 31);
 #pragma unroll 8
-      for (int pp = (tid >> 6) * (BM / 4); pp < ((tid >> 6) + 1) * (BM / 4); ++pp) {
+      for (int pp = (tid >> 6) * (BM / NW); pp < ((tid >> 6) + 1) * (BM / NW); ++pp) {
         T v; *reinterpret_cast<uint16_t*>(&v) = col[pp * 32];
         bsum += ET<T>::ld(&v);
       }
@@ -175,7 +179,10 @@ __global__ __launch_bounds__(256) void conv_wgrad16_kernel(WgradArgs a) {
     if (tid < 64) {
       const int cout_pad_b = gridDim.y * WBCO;
       float* bslab = a.slab + (size_t)gridDim.x * TAPS * cout_pad_b * (gridDim.z * BCI) + (size_t)blockIdx.x * cout_pad_b;
-      bslab[co0 + tid] = (red[tid] + red[tid + 64]) + (red[tid + 128] + red[tid + 192]);
+      float sacc = 0.f;
+#pragma unroll
+      for (int w8 = 0; w8 < NW; ++w8) sacc += red[tid + 64 * w8];
+      bslab[co0 + tid] = sacc;
     }
   }
 
@@ -243,11 +250,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
-template <typename T, int KS, int TH, int TW, int BCI>
+template <typename T, int KS, int TH, int TW, int BCI, int NW = 4>
 static hipError_t launch_wg16(const WgradArgs& a, hipStream_t s) {
   constexpr int PADP = KS / 2, BM = TH * TW, NPH = (TH + 2 * PADP) * (TW + 2 * PADP), TAPS = KS * KS;
   constexpr size_t lds = (size_t)2 * (2 * BM + (BCI / 32) * NPH) * 32 * 2;
-  auto kern = conv_wgrad16_kernel<T, KS, TH, TW, BCI>;
+  auto kern = conv_wgrad16_kernel<T, KS, TH, TW, BCI, NW>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -266,11 +273,11 @@ static hipError_t launch_wg16(const WgradArgs& a, hipStream_t s) {
   char tag[128];
   const bool prof = prof_enabled();
   if (prof) {
-    snprintf(tag, sizeof tag, "conv_wgrad16_kernel<%s,%d,%d,%d,%d>", ET<T>::DT == 1 ? "f16" : "bf16", KS, TH, TW, BCI);
+    snprintf(tag, sizeof tag, "conv_wgrad16_kernel<%s,%d,%d,%d,%d,%d>", ET<T>::DT == 1 ? "f16" : "bf16", KS, TH, TW, BCI, NW);
     const double px = (double)a.B * a.H * a.W;
     prof_record(tag, 2.0 * px * a.Cout * (double)a.Cin * a.taps, px * (a.Cin + a.Cout) * 2 + (double)a.Cout * a.Cin * a.taps * 4, s, true);
   }
-  hipLaunchKernelGGL(kern, dim3(split, gy, gz), dim3(256), lds, s, b);
+  hipLaunchKernelGGL(kern, dim3(split, gy, gz), dim3(64 * NW), lds, s, b);
   if (prof) prof_record(tag, 0, 0, s, false);
   const long total = (long)TAPS * a.Cout * a.Cin;
   const unsigned nbias_blocks = a.dbias0 ? (unsigned)cdiv(a.Cout, 64) : 0u;
@@ -284,7 +291,7 @@ static hipError_t launch_wg16_ks(const WgradArgs& a, hipStream_t s) {
   const bool wide = a.Cin > 32;
   if (a.W % 32 == 0 && a.H % 8 == 0 && wide && getenv("PU_WG_BIG")) return launch_wg16<T, KS, 8, 32, 64>(a, s);   // 256-pixel K tiles: +4 % alone,
                                                                                             // but 152 KB LDS blocks co-residency with conv3
-  if (a.W % 32 == 0 && a.H % 4 == 0) return wide ? launch_wg16<T, KS, 4, 32, 64>(a, s) : launch_wg16<T, KS, 4, 32, 32>(a, s);
+  if (a.W % 32 == 0 && a.H % 4 == 0) return wide ? (getenv("PU_WG_4W") ? launch_wg16<T, KS, 4, 32, 64>(a, s) : launch_wg16<T, KS, 4, 32, 64, 8>(a, s)) : launch_wg16<T, KS, 4, 32, 32>(a, s);
   if (a.W % 16 == 0 && a.H % 8 == 0) return wide ? launch_wg16<T, KS, 8, 16, 64>(a, s) : launch_wg16<T, KS, 8, 16, 32>(a, s);
   if (a.W % 8 == 0 && a.H % 8 == 0) return wide ? launch_wg16<T, KS, 8, 8, 64>(a, s) : launch_wg16<T, KS, 8, 8, 32>(a, s);
   return hipErrorInvalidValue;
