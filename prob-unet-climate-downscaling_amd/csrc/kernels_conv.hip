@@ -693,6 +693,10 @@ static hipError_t launch_conv3_cfg(const ConvArgs& a, hipStream_t s) {
 template <typename T, int KS>
 static hipError_t launch_conv3(const ConvArgs& a, hipStream_t s) {
   if constexpr (sizeof(T) == 2) {
+    // 64 -> 64-class layers: the non-persistent kernel on 128-pixel tiles keeps ~4 blocks per CU resident and beats the
+    // 148 KB-LDS persistent configuration by ~7 %
+    if (a.cin_pk == 2 * KC && a.Cout > 32 && a.Cout <= 64 && a.W % 32 == 0 && a.H % 4 == 0)
+      return launch_conv3_cfg<T, KS, 4, 32, 2, 2>(a, s);
     if (a.cin_pk <= 2 * KC && !getenv("PU_NO_CONV3P")) {       // short-K layers: persistent, weight-resident variant
       hipError_t e = hipErrorNotSupported;
       if (a.W % 32 == 0 && a.H % 8 == 0) e = launch_conv3p<T, KS, 8, 32>(a, s);

@@ -145,20 +145,30 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad16_kernel(WgradArgs a) {
     if (nxt < ntiles) gload(nxt);
     const uint16_t* sDy = lds + cur * BUF + (ct * BM) * 32 + cb;
     const uint16_t* sA = lds + cur * BUF + 2 * BM * 32 + (it * NPH) * 32 + cb;
-#pragma unroll 2
-    for (int kk = 0; kk < BM / 16; ++kk) {
+    // software-pipelined over the K-steps: the transposed reads of step kk+1 are issued as one block before the MFMAs of step
+    // kk (sched_barrier keeps the blocks apart), so they land under those MFMAs instead of stalling their own consumers
+    typename M::Frag fa[2], fb[2][NJ];
+    auto load_step = [&](int kk, int slot) {
       const int m0 = kk * 16 + 8 * h + q, m1 = m0 + 4;
-      const typename M::Frag fa = tr_frag<typename M::Frag>(sDy + m0 * 32, sDy + m1 * 32);
+      fa[slot] = tr_frag<typename M::Frag>(sDy + m0 * 32, sDy + m1 * 32);
       const int h0 = ((m0 / TW) * IW + (m0 % TW)) * 32, h1 = ((m1 / TW) * IW + (m1 % TW)) * 32;
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         const int t = tap0 + j;
-        if (t < TAPS) {
-          const int toff = ((t / KS) * IW + (t % KS)) * 32;
-          const typename M::Frag fb = tr_frag<typename M::Frag>(sA + h0 + toff, sA + h1 + toff);
-          acc[j] = M::mfma(fa, fb, acc[j]);
-        }
+        const int tt = t < TAPS ? t : 0;
+        const int toff = ((tt / KS) * IW + (tt % KS)) * 32;
+        fb[slot][j] = tr_frag<typename M::Frag>(sA + h0 + toff, sA + h1 + toff);
       }
+    };
+    load_step(0, 0);
+#pragma unroll
+    for (int kk = 0; kk < BM / 16; ++kk) {
+      if (kk + 1 < BM / 16) load_step(kk + 1, (kk + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        if (tap0 + j < TAPS) acc[j] = M::mfma(fa[kk & 1], fb[kk & 1][j], acc[j]);
+      __builtin_amdgcn_sched_barrier(0);
     }
     if (do_bias) {
       const uint16_t* col = lds + cur * BUF + (((tid & 63) >> 5) * BM) * 32 + (tid & 31);

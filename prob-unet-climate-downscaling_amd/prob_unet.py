@@ -417,16 +417,19 @@ class ProbabilisticUNet(nn.Module):
         if self._dp_world > 1:
             from .dp import allreduce_mean_
             allreduce_mean_(eg, self._dp_group, self.dp_bucket_elems)
-        if g is not None:
-            eg = eg * g.reshape(())
         P = self._params_in(lo, hi)
         views = self._grad_views(lo, hi)
         fresh = all(p.grad is None for p, _, _ in P[:4]) and P[-1][0].grad is None and P[len(P) // 2][0].grad is None
         if fresh and all(p.grad is None for p, _, _ in P):
-            self._flat_grad[lo:hi].copy_(eg)
+            if g is not None:
+                torch.mul(eg, g.reshape(()), out=self._flat_grad[lo:hi])      # one pass: scale by grad_output while copying
+            else:
+                self._flat_grad[lo:hi].copy_(eg)
             for (p, off, n), v in zip(P, views):
                 p.grad = v
         else:
+            if g is not None:
+                eg = eg * g.reshape(())
             for p, off, n in P:
                 ge = eg[off - lo:off - lo + n].view(p.shape)
                 if p.grad is None:
