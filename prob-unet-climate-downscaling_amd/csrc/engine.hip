@@ -163,7 +163,7 @@ static void setup_gn(pu_ctx* c, GNL& n, int C, long HW, int64_t g_off, int64_t b
   n.dropout = dropout; n.drop_stream = stream;
   const int mb = c->cfg.max_batch;
   n.stat = alloc_f32(c, (size_t)mb * n.G * 2);
-  n.coef = alloc_f32(c, (size_t)mb * C * 2);
+  n.coef = alloc_f32(c, (size_t)mb * C * 4);
   if (C > c->max_gn_c) c->max_gn_c = C;
 }
 
@@ -1030,7 +1030,7 @@ static int op_gn_t(int resample, int B, int C, int H, int W, const float* x, con
   const long nin = (long)B * H * W * C, nout = (long)B * OH * OW * C;
   T *xb = nullptr, *yb = nullptr, *dyb = nullptr, *dxb = nullptr, *dvb = nullptr; float* ws = nullptr;
   const int G = gn_groups(C), nchunk = gn_chunks((long)H * W);
-  const size_t nws = (size_t)B * nchunk * C * 2 * 2 + (size_t)B * G * 2 + (size_t)B * C * 2 + (size_t)B * C * 3;
+  const size_t nws = (size_t)B * nchunk * C * 2 * 2 + (size_t)B * G * 2 + 4 + (size_t)B * C * 4 + (size_t)B * C * 3;
   GNArgs a; GNBwdArgs bw; TV tx, ty;
   CK0(hipMalloc(&xb, nin * esz)); CK0(hipMalloc(&yb, nout * esz)); CK0(hipMalloc(&dyb, nout * esz)); CK0(hipMalloc(&dxb, nin * esz));
   CK0(hipMalloc(&dvb, nin * esz)); CK0(hipMalloc(&ws, nws * sizeof(float)));
@@ -1039,7 +1039,7 @@ static int op_gn_t(int resample, int B, int C, int H, int W, const float* x, con
   memset(&a, 0, sizeof a);
   a.x = tx; a.y = ty; a.G = G; a.eps = 1e-5f; a.gamma = gamma; a.beta = beta; a.scale = ss; a.shift = ss ? ss + C : nullptr; a.resample = resample;
   a.drop_p = resample == RS_NONE ? drop_p : 0.f; a.drop_seed = drop_seed; a.drop_stream = 7;
-  a.part = ws; a.nchunk = nchunk; a.stat = ws + (size_t)B * nchunk * C * 2; a.coef = a.stat + (size_t)B * G * 2;
+  a.part = ws; a.nchunk = nchunk; a.stat = ws + (size_t)B * nchunk * C * 2; a.coef = a.stat + (((size_t)B * G * 2 + 3) & ~(size_t)3);
   CK0(launch_nchw_to_nhwc<T>(x, (long)C * H * W, C, nullptr, 0, tx, s));
   CK0(launch_gn_fwd<T>(a, s));
   CK0(launch_nhwc_to_nchw<T>(ty, C, y, 0, s));
@@ -1049,7 +1049,7 @@ static int op_gn_t(int resample, int B, int C, int H, int W, const float* x, con
     memset(&bw, 0, sizeof bw);
     bw.f = a; bw.dy = tdy; bw.dv = tdv; bw.dx = tdx; bw.accumulate = 0;
     bw.dgamma = dgamma; bw.dbeta = dbeta; bw.dscale = ss ? dss : nullptr; bw.dshift = ss ? dss + C : nullptr;
-    bw.part2 = a.coef + (size_t)B * C * 2; bw.coef2 = bw.part2 + (size_t)B * nchunk * C * 2; bw.inv_scale = 1.f;
+    bw.part2 = a.coef + (size_t)B * C * 4; bw.coef2 = bw.part2 + (size_t)B * nchunk * C * 2; bw.inv_scale = 1.f;
     CK0(hipMemsetAsync(dgamma, 0, C * sizeof(float), s)); CK0(hipMemsetAsync(dbeta, 0, C * sizeof(float), s));
     if (ss) CK0(hipMemsetAsync(dss, 0, 2 * C * sizeof(float), s));
     CK0(launch_gn_bwd<T>(bw, s));

@@ -213,6 +213,17 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs a) {
     __syncthreads();
     if (c0 + KC < a.cin_pk) gload(c0 + KC);        // in flight during the MFMAs below
     if (c0 < a.Cin) {
+      // fp32 engine: two-level summation (each 32-channel chunk into a fresh accumulator, then one add into the total) keeps
+      // the rounding error of the exact-fp32 MFMA chain from growing with the full K = 9 Cin
+      f32x16 part[NTN][NTM];
+      if constexpr (sizeof(T) == 4) {
+#pragma unroll
+        for (int i = 0; i < NTN; ++i)
+#pragma unroll
+          for (int j = 0; j < NTM; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) part[i][j][r] = 0.f;
+      }
 #pragma unroll
       for (int t = 0; t < TAPS; ++t) {
         const int toff = ((t / KS) * IW + (t % KS)) * KCP;
@@ -227,8 +238,19 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
           for (int i = 0; i < NTN; ++i)
 #pragma unroll
-            for (int j = 0; j < NTM; ++j) acc[i][j] = M::mfma(fa[i], fb[j], acc[i][j]);
+            for (int j = 0; j < NTM; ++j) {
+              if constexpr (sizeof(T) == 4) part[i][j] = M::mfma(fa[i], fb[j], part[i][j]);
+              else acc[i][j] = M::mfma(fa[i], fb[j], acc[i][j]);
+            }
         }
+      }
+      if constexpr (sizeof(T) == 4) {
+#pragma unroll
+        for (int i = 0; i < NTN; ++i)
+#pragma unroll
+          for (int j = 0; j < NTM; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] += part[i][j][r];
       }
     }
   }
@@ -825,11 +847,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   const T* dy = reinterpret_cast<const T*>(a.dy);
   const T* in = reinterpret_cast<const T*>(a.in);
 
-  f32x16 acc[NJ];
+  f32x16 acc[NJ], part[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; ++j)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    for (int r = 0; r < 16; ++r) { acc[j][r] = 0.f; part[j][r] = 0.f; }
 
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     int pt = tile;
@@ -894,10 +916,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
             const int ct = tl & 1, t = tl >> 1;
             const int toff = (t / KS) * IW + (t % KS);
             const float bv = reinterpret_cast<const float*>(sA)[(hh + toff) * AS + (l & 31)];
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ct ? a1 : a0, bv, acc[j], 0, 0, 0);
+            part[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(ct ? a1 : a0, bv, part[j], 0, 0, 0);
           }
         }
       }
+    }
+    if constexpr (sizeof(T) == 4) {           // two-level summation: one pixel tile per partial accumulator
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[j][r] += part[j][r]; part[j][r] = 0.f; }
     }
   }
   // ---- flush: atomics into the fp32 gradient in the reference layout [Cout][Cin][KS][KS]

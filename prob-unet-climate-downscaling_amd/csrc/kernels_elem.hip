@@ -94,14 +94,17 @@ __global__ __launch_bounds__(256) void chan_partial_kernel(TV x, float* __restri
   const long per = (npix + nchunk - 1) / nchunk;
   const long p0 = (long)chunk * per, p1 = min(npix, p0 + per);
   const T* xp = reinterpret_cast<const T*>(x.p) + (per_batch ? (long)b * x.H * x.W * x.ld : 0);
-  float s1[VEC], s2[VEC];
+  float s1[VEC], s2[VEC], sh[VEC];
 #pragma unroll
-  for (int e = 0; e < VEC; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+  for (int e = 0; e < VEC; ++e) { s1[e] = 0.f; s2[e] = 0.f; sh[e] = 0.f; }
   if (pl < PL) {
+    // statistics (SQ): sums of (x - shift) with shift = the sample's first pixel of that channel, so that E[d^2] - E[d]^2
+    // does not cancel when |mean| >> std; gn_finalize undoes the shift exactly
+    if (SQ) unpack<T>(ldv<T>(xp + cv * VEC), sh);
     for (long p = p0 + pl; p < p1; p += PL) {
       float v[VEC]; unpack<T>(ldv<T>(xp + p * x.ld + cv * VEC), v);
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) { s1[e] += v[e]; if (SQ) s2[e] += v[e] * v[e]; }
+      for (int e = 0; e < VEC; ++e) { const float d = v[e] - sh[e]; s1[e] += d; if (SQ) s2[e] += d * d; }
     }
   }
   // buf layout [pl][c][2]
@@ -120,61 +123,68 @@ __global__ __launch_bounds__(256) void chan_partial_kernel(TV x, float* __restri
   }
 }
 
-__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ part, int nchunk, int C, int G, long HW, float eps,
+template <typename T>
+__global__ __launch_bounds__(256) void gn_finalize_kernel(TV x, const float* __restrict__ part, int nchunk, int G, float eps,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           const float* __restrict__ scale, const float* __restrict__ shift,
                                                           float* __restrict__ stat, float* __restrict__ coef) {
-  __shared__ double cs[1024 * 2];
+  __shared__ double cs[1024 * 2];      // per channel: mean_c, M2_c
   __shared__ float gs[64];
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int b = blockIdx.x, tid = threadIdx.x, C = x.C;
+  const long HW = (long)x.H * x.W;
+  const T* x0 = reinterpret_cast<const T*>(x.p) + (long)b * HW * x.ld;      // first pixel of the sample = the shift
   for (int c = tid; c < C; c += 256) {
     double a = 0, q = 0;
     for (int k = 0; k < nchunk; ++k) { const float* pp = part + (((long)b * nchunk + k) * C + c) * 2; a += pp[0]; q += pp[1]; }
-    cs[c * 2] = a; cs[c * 2 + 1] = q;
+    const double n = (double)HW, sh = (double)ET<T>::ld(x0 + c);
+    cs[c * 2] = sh + a / n;                      // channel mean
+    cs[c * 2 + 1] = q - a * a / n;               // channel sum of squared deviations
   }
   __syncthreads();
   const int cpg = C / G;
   if (tid < G) {
-    double a = 0, q = 0;
-    for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { a += cs[c * 2]; q += cs[c * 2 + 1]; }
-    const double n = (double)cpg * (double)HW;
-    const double mean = a / n;
-    double var = q / n - mean * mean; if (var < 0) var = 0;
+    double m = 0;
+    for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) m += cs[c * 2];
+    m /= cpg;
+    double M2 = 0;
+    for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) { const double d = cs[c * 2] - m; M2 += cs[c * 2 + 1] + (double)HW * d * d; }
+    double var = M2 / ((double)cpg * (double)HW); if (var < 0) var = 0;
     const float rstd = (float)(1.0 / sqrt(var + (double)eps));
-    gs[tid * 2] = (float)mean; gs[tid * 2 + 1] = rstd;
-    stat[((long)b * G + tid) * 2] = (float)mean; stat[((long)b * G + tid) * 2 + 1] = rstd;
+    gs[tid * 2] = (float)m; gs[tid * 2 + 1] = rstd;
+    stat[((long)b * G + tid) * 2] = (float)m; stat[((long)b * G + tid) * 2 + 1] = rstd;
   }
   __syncthreads();
+  // y = A (x - mean_g) + Bp   (the mean is subtracted from x before scaling: no cancellation against a folded offset)
   for (int c = tid; c < C; c += 256) {
     const int g = c / cpg;
-    const float mean = gs[g * 2], rstd = gs[g * 2 + 1];
-    const float s = scale ? scale[c] : 0.f, t = shift ? shift[c] : 0.f;
-    const float A = rstd * gamma[c] * (1.f + s);
-    const float Bc = (beta[c] - mean * rstd * gamma[c]) * (1.f + s) + t;
-    coef[((long)b * C + c) * 2] = A; coef[((long)b * C + c) * 2 + 1] = Bc;
+    const float rstd = gs[g * 2 + 1];
+    const float sc = scale ? scale[c] : 0.f, t = shift ? shift[c] : 0.f;
+    float4 o4; o4.x = rstd * gamma[c] * (1.f + sc); o4.y = beta[c] * (1.f + sc) + t; o4.z = gs[g * 2]; o4.w = rstd;
+    reinterpret_cast<float4*>(coef)[(long)b * C + c] = o4;      // per channel: (A, Bp, group mean, group rstd)
   }
 }
 
 template <typename T, int RS>
-__global__ void gn_apply_kernel(GNArgs a) {
+__global__ __launch_bounds__(256) void gn_apply_kernel(GNArgs a) {
+  // grid (pixel chunks, B); a thread keeps ONE channel vector (its coefficients live in registers) and walks pixels
   constexpr int VEC = ET<T>::VEC;
-  const int C = a.x.C, CV = C / VEC;
+  const int C = a.x.C, CV = C / VEC, PL = 256 / CV;
+  const int tid = threadIdx.x, cv = tid % CV, pl = tid / CV, b = blockIdx.y;
+  if (pl >= PL) return;
   const int OH = a.y.H, OW = a.y.W;
-  const long total = (long)a.x.B * OH * OW * CV;
+  const long OHW = (long)OH * OW;
+  const long per = (OHW + gridDim.x - 1) / gridDim.x;
+  const long p0 = (long)blockIdx.x * per, p1 = min(OHW, p0 + per);
   const T* xp = reinterpret_cast<const T*>(a.x.p);
   T* yp = reinterpret_cast<T*>(a.y.p);
   const float keep = 1.f - a.drop_p, inv_keep = a.drop_p > 0.f ? 1.f / keep : 1.f;
   const uint32_t dkey = drop_key(a.drop_seed, a.drop_stream), dthr = drop_thr16(keep);
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int cv = (int)(i % CV);
-    long p = i / CV;
-    const int ox = (int)(p % OW); p /= OW;
-    const int oy = (int)(p % OH);
-    const int b = (int)(p / OH);
-    float A[VEC], Bc[VEC];
-    const float* cf = a.coef + ((long)b * C + cv * VEC) * 2;
+  float A[VEC], Bc[VEC], mu[VEC];
+  const float4* cf = reinterpret_cast<const float4*>(a.coef) + ((long)b * C + cv * VEC);
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) { A[e] = cf[2 * e]; Bc[e] = cf[2 * e + 1]; }
+  for (int e = 0; e < VEC; ++e) { const float4 q4 = cf[e]; A[e] = q4.x; Bc[e] = q4.y; mu[e] = q4.z; }
+  for (long p = p0 + pl; p < p1; p += PL) {
+    const int oy = (int)(p / OW), ox = (int)(p - (long)oy * OW);
     float o[VEC];
     if (RS == RS_DOWN) {
 #pragma unroll
@@ -184,15 +194,15 @@ __global__ void gn_apply_kernel(GNArgs a) {
         const int iy = 2 * oy + (q >> 1), ix = 2 * ox + (q & 1);
         float v[VEC]; unpack<T>(ldv<T>(xp + (((long)b * a.x.H + iy) * a.x.W + ix) * a.x.ld + cv * VEC), v);
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) o[e] += 0.25f * silu_f(A[e] * v[e] + Bc[e]);
+        for (int e = 0; e < VEC; ++e) o[e] += 0.25f * silu_f<sizeof(T) == 4>(A[e] * (v[e] - mu[e]) + Bc[e]);
       }
     } else {
       const int iy = RS == RS_UP ? oy >> 1 : oy, ix = RS == RS_UP ? ox >> 1 : ox;
       float v[VEC]; unpack<T>(ldv<T>(xp + (((long)b * a.x.H + iy) * a.x.W + ix) * a.x.ld + cv * VEC), v);
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) o[e] = silu_f(A[e] * v[e] + Bc[e]);
+      for (int e = 0; e < VEC; ++e) o[e] = silu_f<sizeof(T) == 4>(A[e] * (v[e] - mu[e]) + Bc[e]);
       if (RS == RS_NONE && a.drop_p > 0.f) {
-        const uint64_t base = (((uint64_t)(b + a.b0) * OH + oy) * OW + ox) * (uint64_t)C + (uint64_t)cv * VEC;
+        const uint64_t base = ((uint64_t)(b + a.b0) * OHW + p) * (uint64_t)C + (uint64_t)cv * VEC;
 #pragma unroll
         for (int e = 0; e < VEC; e += 2) {
           const uint32_t r = drop_pair(dkey, base + e);
@@ -201,10 +211,18 @@ __global__ void gn_apply_kernel(GNArgs a) {
         }
       }
     }
-    stv<T>(yp + (((long)b * OH + oy) * OW + ox) * a.y.ld + cv * VEC, pack<T>(o));
+    stv<T>(yp + ((long)b * OHW + p) * a.y.ld + cv * VEC, pack<T>(o));
   }
 }
 
+// pixel-chunk count for the (chunks, B) elementwise GN kernels: ~4 pixels per thread, at most ~4096 blocks in flight
+static inline unsigned gn_pix_blocks(long hw, int CV, int B) {
+  const int PL = 256 / CV;
+  long n = (hw + (long)PL * 4 - 1) / ((long)PL * 4);
+  const long cap = 4096 / (B > 0 ? B : 1) > 0 ? 4096 / (B > 0 ? B : 1) : 1;
+  if (n > cap) n = cap;
+  return (unsigned)(n < 1 ? 1 : n);
+}
 static inline unsigned ew_grid(long total) { long g = (total + 255) / 256; return (unsigned)(g > 8192 ? 8192 : (g < 1 ? 1 : g)); }
 
 // Optional batch-chunked launches (PU_GN_CHUNK_MB=<n>): GroupNorm statistics are per sample, so a big tensor can be processed
@@ -228,7 +246,7 @@ static inline int gn_batch_chunk(const TV& x, size_t esz) {
 static inline GNArgs gn_sub(const GNArgs& a, int b0, int nb, size_t esz) {
   GNArgs q = a;
   q.x = tv_batch(a.x, b0, nb, esz); q.y = tv_batch(a.y, b0, nb, esz);
-  q.part = a.part + (size_t)b0 * a.nchunk * a.x.C * 2; q.stat = a.stat + (size_t)b0 * a.G * 2; q.coef = a.coef + (size_t)b0 * a.x.C * 2;
+  q.part = a.part + (size_t)b0 * a.nchunk * a.x.C * 2; q.stat = a.stat + (size_t)b0 * a.G * 2; q.coef = a.coef + (size_t)b0 * a.x.C * 4;
   q.b0 = a.b0 + b0;
   return q;
 }
@@ -241,12 +259,13 @@ hipError_t launch_gn_fwd(const GNArgs& a0, hipStream_t s) {
     const int nb = min(step, a0.x.B - b0);
     const GNArgs a = gn_sub(a0, b0, nb, sizeof(T));
     hipLaunchKernelGGL((chan_partial_kernel<T, true>), dim3(a.nchunk, a.x.B), dim3(256), 0, s, a.x, a.part, a.nchunk, 1);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(a.x.B), dim3(256), 0, s, a.part, a.nchunk, a.x.C, a.G, HW, a.eps, a.gamma, a.beta,
+    hipLaunchKernelGGL(gn_finalize_kernel<T>, dim3(a.x.B), dim3(256), 0, s, a.x, a.part, a.nchunk, a.G, a.eps, a.gamma, a.beta,
                        a.scale, a.shift, a.stat, a.coef);
-    const long total = (long)a.y.B * a.y.H * a.y.W * (a.x.C / ET<T>::VEC);
-    if (a.resample == RS_NONE) hipLaunchKernelGGL((gn_apply_kernel<T, RS_NONE>), dim3(ew_grid(total)), dim3(256), 0, s, a);
-    else if (a.resample == RS_DOWN) hipLaunchKernelGGL((gn_apply_kernel<T, RS_DOWN>), dim3(ew_grid(total)), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((gn_apply_kernel<T, RS_UP>), dim3(ew_grid(total)), dim3(256), 0, s, a);
+    (void)HW;
+    const dim3 ga(gn_pix_blocks((long)a.y.H * a.y.W, a.x.C / ET<T>::VEC, a.x.B), a.x.B);
+    if (a.resample == RS_NONE) hipLaunchKernelGGL((gn_apply_kernel<T, RS_NONE>), ga, dim3(256), 0, s, a);
+    else if (a.resample == RS_DOWN) hipLaunchKernelGGL((gn_apply_kernel<T, RS_DOWN>), ga, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((gn_apply_kernel<T, RS_UP>), ga, dim3(256), 0, s, a);
   }
   return hipGetLastError();
 }
@@ -258,7 +277,7 @@ hipError_t launch_gn_fwd(const GNArgs& a0, hipStream_t s) {
 // i.e. 4 tensor reads + 1 write instead of the 4 + 2 of a stored-dv formulation.
 template <typename T, int RS>
 __device__ __forceinline__ void gn_dv(const GNArgs& f, const TV& dy, int b, int y, int x, long p, int cv, const float* A, const float* Bc,
-                                      const float* xv, float keep, float inv_keep, float* dv) {
+                                      const float* mu, const float* xv, float keep, float inv_keep, float* dv) {
   constexpr int VEC = ET<T>::VEC;
   const int H = f.x.H, W = f.x.W, C = f.x.C;
   const long HW = (long)H * W;
@@ -292,7 +311,7 @@ __device__ __forceinline__ void gn_dv(const GNArgs& f, const TV& dy, int b, int 
     }
   }
 #pragma unroll
-  for (int e = 0; e < VEC; ++e) dv[e] = dh[e] * dsilu_f(A[e] * xv[e] + Bc[e]);
+  for (int e = 0; e < VEC; ++e) dv[e] = dh[e] * dsilu_f<sizeof(T) == 4>(A[e] * (xv[e] - mu[e]) + Bc[e]);
 }
 
 template <typename T, int RS>
@@ -308,23 +327,21 @@ __global__ __launch_bounds__(256) void gn_bwd_pass1_kernel(GNBwdArgs a) {
   const long per = (HW + f.nchunk - 1) / f.nchunk;
   const long p0 = (long)chunk * per, p1 = min(HW, p0 + per);
   const T* xp = reinterpret_cast<const T*>(f.x.p);
-  const int cpg = C / f.G;
   float A[VEC], Bc[VEC], mean[VEC], rstd[VEC], s1[VEC], s2[VEC];
   const float keep = 1.f - f.drop_p, inv_keep = f.drop_p > 0.f ? 1.f / keep : 1.f;
   if (pl < PL) {
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
       const int c = cv * VEC + e;
-      A[e] = f.coef[((long)b * C + c) * 2]; Bc[e] = f.coef[((long)b * C + c) * 2 + 1];
-      const int g = c / cpg;
-      mean[e] = f.stat[((long)b * f.G + g) * 2]; rstd[e] = f.stat[((long)b * f.G + g) * 2 + 1];
+      const float4 q4 = reinterpret_cast<const float4*>(f.coef)[(long)b * C + c];
+      A[e] = q4.x; Bc[e] = q4.y; mean[e] = q4.z; rstd[e] = q4.w;
       s1[e] = 0.f; s2[e] = 0.f;
     }
     for (long p = p0 + pl; p < p1; p += PL) {
       const int y = (int)(p / W), x = (int)(p % W);
       float xv[VEC], dv[VEC];
       unpack<T>(ldv<T>(xp + ((long)b * HW + p) * f.x.ld + cv * VEC), xv);
-      gn_dv<T, RS>(f, a.dy, b, y, x, p, cv, A, Bc, xv, keep, inv_keep, dv);
+      gn_dv<T, RS>(f, a.dy, b, y, x, p, cv, A, Bc, mean, xv, keep, inv_keep, dv);
 #pragma unroll
       for (int e = 0; e < VEC; ++e) { s1[e] += dv[e]; s2[e] += dv[e] * (xv[e] - mean[e]) * rstd[e]; }
     }
@@ -368,9 +385,10 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(GNBwdArgs a) {
     const float gp = f.gamma[c] * (1.f + (f.scale ? f.scale[c] : 0.f));
     const float m1 = gm[g * 2], m2 = gm[g * 2 + 1];
     float* o = a.coef2 + ((long)b * C + c) * 3;
-    o[0] = rstd * gp;
+    o[0] = rstd * gp;                  // dx = o0 dv + o1 (x - mean) + o2
     o[1] = -rstd * rstd * m2;
-    o[2] = -rstd * m1 + rstd * rstd * m2 * mean;
+    o[2] = -rstd * m1;
+    (void)mean;
     // parameter gradients: this sample's contribution (fp32 atomics over the B samples; ADDED into the flat gradient)
     const float S1 = cs[c * 2] * a.inv_scale, S2 = cs[c * 2 + 1] * a.inv_scale;
     const float sc = f.scale ? f.scale[c] : 0.f;
@@ -382,34 +400,35 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(GNBwdArgs a) {
 }
 
 template <typename T, int RS>
-__global__ void gn_bwd_pass2_kernel(GNBwdArgs a) {
+__global__ __launch_bounds__(256) void gn_bwd_pass2_kernel(GNBwdArgs a) {
   constexpr int VEC = ET<T>::VEC;
   const GNArgs& f = a.f;
-  const int C = f.x.C, CV = C / VEC, W = f.x.W;
+  const int C = f.x.C, CV = C / VEC, PL = 256 / CV, W = f.x.W;
+  const int tid = threadIdx.x, cv = tid % CV, pl = tid / CV, b = blockIdx.y;
+  if (pl >= PL) return;
   const long HW = (long)f.x.H * W;
-  const long total = (long)f.x.B * HW * CV;
+  const long per = (HW + gridDim.x - 1) / gridDim.x;
+  const long p0 = (long)blockIdx.x * per, p1 = min(HW, p0 + per);
   const T* xp = reinterpret_cast<const T*>(f.x.p);
   T* dxp = reinterpret_cast<T*>(a.dx.p);
   const float keep = 1.f - f.drop_p, inv_keep = f.drop_p > 0.f ? 1.f / keep : 1.f;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int cv = (int)(i % CV);
-    const long bp = i / CV;
-    const int b = (int)(bp / HW);
-    const long p = bp - (long)b * HW;
-    const float* cf = a.coef2 + ((long)b * C + cv * VEC) * 3;
-    const float* c1 = f.coef + ((long)b * C + cv * VEC) * 2;
-    float A[VEC], Bc[VEC], xv[VEC], dv[VEC], o[VEC];
+  float A[VEC], Bc[VEC], mu[VEC], c0[VEC], c1[VEC], c2[VEC];
+  const float4* q1 = reinterpret_cast<const float4*>(f.coef) + ((long)b * C + cv * VEC);
+  const float* q2 = a.coef2 + ((long)b * C + cv * VEC) * 3;
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) { A[e] = c1[2 * e]; Bc[e] = c1[2 * e + 1]; }
+  for (int e = 0; e < VEC; ++e) { const float4 q4 = q1[e]; A[e] = q4.x; Bc[e] = q4.y; mu[e] = q4.z; c0[e] = q2[3 * e]; c1[e] = q2[3 * e + 1]; c2[e] = q2[3 * e + 2]; }
+  for (long p = p0 + pl; p < p1; p += PL) {
+    const long bp = (long)b * HW + p;
+    float xv[VEC], dv[VEC], o[VEC];
     unpack<T>(ldv<T>(xp + bp * f.x.ld + cv * VEC), xv);
-    gn_dv<T, RS>(f, a.dy, b, (int)(p / W), (int)(p % W), p, cv, A, Bc, xv, keep, inv_keep, dv);
+    gn_dv<T, RS>(f, a.dy, b, (int)(p / W), (int)(p % W), p, cv, A, Bc, mu, xv, keep, inv_keep, dv);
     if (a.accumulate) unpack<T>(ldv<T>(dxp + bp * a.dx.ld + cv * VEC), o);
     else {
 #pragma unroll
       for (int e = 0; e < VEC; ++e) o[e] = 0.f;
     }
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) o[e] += cf[3 * e] * dv[e] + cf[3 * e + 1] * xv[e] + cf[3 * e + 2];
+    for (int e = 0; e < VEC; ++e) o[e] += c0[e] * dv[e] + c1[e] * (xv[e] - mu[e]) + c2[e];
     stv<T>(dxp + bp * a.dx.ld + cv * VEC, pack<T>(o));
   }
 }
@@ -429,10 +448,10 @@ hipError_t launch_gn_bwd(const GNBwdArgs& a0, hipStream_t s) {
     else if (f.resample == RS_DOWN) hipLaunchKernelGGL((gn_bwd_pass1_kernel<T, RS_DOWN>), g1, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((gn_bwd_pass1_kernel<T, RS_UP>), g1, dim3(256), 0, s, a);
     hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(f.x.B), dim3(256), 0, s, a);
-    const long total = (long)f.x.B * f.x.H * f.x.W * (f.x.C / ET<T>::VEC);
-    if (f.resample == RS_NONE) hipLaunchKernelGGL((gn_bwd_pass2_kernel<T, RS_NONE>), dim3(ew_grid(total)), dim3(256), 0, s, a);
-    else if (f.resample == RS_DOWN) hipLaunchKernelGGL((gn_bwd_pass2_kernel<T, RS_DOWN>), dim3(ew_grid(total)), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((gn_bwd_pass2_kernel<T, RS_UP>), dim3(ew_grid(total)), dim3(256), 0, s, a);
+    const dim3 g2(gn_pix_blocks((long)f.x.H * f.x.W, f.x.C / ET<T>::VEC, f.x.B), f.x.B);
+    if (f.resample == RS_NONE) hipLaunchKernelGGL((gn_bwd_pass2_kernel<T, RS_NONE>), g2, dim3(256), 0, s, a);
+    else if (f.resample == RS_DOWN) hipLaunchKernelGGL((gn_bwd_pass2_kernel<T, RS_DOWN>), g2, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((gn_bwd_pass2_kernel<T, RS_UP>), g2, dim3(256), 0, s, a);
   }
   return hipGetLastError();
 }

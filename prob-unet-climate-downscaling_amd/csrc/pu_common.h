@@ -86,10 +86,14 @@ struct TV {
   __host__ __device__ size_t pixels() const { return (size_t)B * H * W; }
 };
 
-// SiLU and its derivative with the hardware reciprocal (v_rcp_f32, 1 ulp) instead of an IEEE division
-__device__ __forceinline__ float sigmoid_f(float v) { return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
-__device__ __forceinline__ float silu_f(float v) { return v * sigmoid_f(v); }
-__device__ __forceinline__ float dsilu_f(float v) { const float s = sigmoid_f(v); return s * (1.0f + v * (1.0f - s)); }
+// SiLU and its derivative.  16-bit engines: hardware exp2 / reciprocal (v_exp_f32, v_rcp_f32, ~1 ulp).
+// fp32 parity engine (PRECISE): libm expf and an IEEE division, so that the path stays at the fp32 noise floor.
+template <bool PRECISE> __device__ __forceinline__ float sigmoid_f(float v) {
+  if (PRECISE) return 1.0f / (1.0f + expf(-v));
+  return __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+}
+template <bool PRECISE> __device__ __forceinline__ float silu_f(float v) { return v * sigmoid_f<PRECISE>(v); }
+template <bool PRECISE> __device__ __forceinline__ float dsilu_f(float v) { const float s = sigmoid_f<PRECISE>(v); return s * (1.0f + v * (1.0f - s)); }
 
 // Counter-hash RNG for dropout, regenerated (never stored) in backward.  One 32-bit hash serves TWO consecutive elements
 // (16 bits each): keep iff u16 < thr16 = round(keep * 65536).  key = drop_key(seed, stream) is computed once per kernel.

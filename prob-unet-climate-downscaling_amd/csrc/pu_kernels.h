@@ -55,7 +55,7 @@ struct GNArgs {
   const float* scale; const float* shift;         // fp32 [C] each or null (adaptive: y = silu(gn*(1+scale)+shift))
   int resample;
   float drop_p; uint64_t drop_seed; uint32_t drop_stream;   // drop_p == 0 -> no dropout
-  // workspaces (fp32): part [B][nchunk][C][2], stat [B][G][2] (mean, rstd), coef [B][C][2] (A, Bc)
+  // workspaces (fp32): part [B][nchunk][C][2], stat [B][G][2] (mean, rstd), coef [B][C][4] (A, Bp, mean, rstd; 16-byte aligned)
   float* part; float* stat; float* coef; int nchunk;
   int b0;                     // batch offset of this launch inside the tensor (batch-chunked launches; keeps the dropout index global)
 };

@@ -300,3 +300,38 @@ def test_flat_adamw_matches_reference_step(name):
                 assert abs(mine["sum"] - cs["sum"]) <= 1e-5 * max(1.0, cs["abssum"]), k
     a = torch.cat([p.detach().flatten() for p in m.parameters()]); b = torch.cat([p.detach().flatten() for p in twin.parameters()])
     assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(b.abs().max()))
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_reference_3to3_config_nonsquare_batch1(dtype):
+    """The configuration the reference actually trains (main.py:35-45: 3 -> 3 planes, num_filters [32,64,128,256],
+    model_channels 32, channel_mult [1,2,4,8]) on a NON-square 64x128 field, batch 1 and batch 3, latent 32, M = 4,
+    against the oracle (seeded closed-form inputs)."""
+    cfg = O.Config(3, 3, 32, [32, 64, 128, 256], 32, [1, 2, 4, 8])
+    P = filled_params(cfg)
+    for B in (1, 3):
+        yy, xx = torch.meshgrid(torch.arange(64.), torch.arange(128.), indexing="ij")
+        x = torch.stack([torch.stack([torch.sin(0.13 * (c + 1) * xx + 0.09 * (b + 2) * yy) + 0.3 * torch.cos(0.31 * yy * (c + 1)) for c in range(3)]) for b in range(B)])
+        y = 0.6 * x + 0.3 * torch.sin(1.3 * xx - 0.7 * yy)[None, None]
+        eps = make_eps(4, B, 32)
+        m = pa.ProbabilisticUNet(3, 3, 32, [32, 64, 128, 256], 32, [1, 2, 4, 8], 0.7, 1.3, 0.0, dtype=dtype, init=False)
+        m.load_state_dict(P); m = m.to(DEV).train(); m.dropout = 0.0
+        total, recon, kl = m.elbo(x.to(DEV), y.to(DEV), None, M=4, eps=eps.to(DEV))
+        total.backward()
+        r, og = O.elbo_with_grads(P, cfg, x, y, eps, beta0=0.7, beta1=1.3)
+        if dtype == "f32":
+            assert_close(total.detach().cpu(), r["total"], what="total"); assert_close(kl.cpu(), r["kl"], what="kl")
+            assert_close(recon[0], r["recon"], what="crps")
+            gr = grads_of(m)
+            rels = []
+            for k, v in og.items():
+                if float(v.norm()) < 1e-7: continue
+                rels.append(float((gr[k].double() - v.double()).norm() / v.double().norm()))
+            assert max(rels) < 3e-2 and float(np.median(rels)) < 2e-3, (max(rels), float(np.median(rels)))
+        else:
+            assert_close(recon[0], r["recon"], rtol=5e-2, atol=2e-2, what="crps f16")
+            assert_close(kl.cpu(), r["kl"], rtol=1e-1, atol=5e-2, what="kl f16")
+        with torch.no_grad():
+            m.eval()
+            out = m(x.to(DEV), training=False)
+            assert out.shape == (B, 3, 64, 128) and torch.isfinite(out).all()
