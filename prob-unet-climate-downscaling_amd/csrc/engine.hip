@@ -41,6 +41,10 @@ struct Block {
   int cin = 0, cout = 0; bool up = false, down = false; int skip = SK_NONE;
   Act x, a0, c0, h1, out, skin;
   GNL n0, n1; ConvL conv0, conv1, skipc;
+  // GroupNorm statistics fused into the producing convolutions (16-bit engines): rows written by the final writer of `out`
+  // (conv1, or conv0 of the stem) and of `c0` (conv0); sl_* = slot count per image reported by the launcher for this forward
+  float *st_out = nullptr, *st_c0 = nullptr; int cap_out = 0, cap_c0 = 0, sl_out = 0, sl_c0 = 0;
+  int src0 = -1, src1 = -1;              // producers of x: index into enc (>= 0) or dec (1000 + j); src1 = skip half of a concat
 };
 struct GaussNet {
   std::vector<ConvL> convs; std::vector<Act> outs; std::vector<Act> ins;   // ins[i] is the input of conv i
@@ -75,6 +79,7 @@ struct pu_ctx {
   int max_gn_c = 0;
   float inv_scale = 1.f;            // 1 / (loss scale) applied to every parameter-gradient write of the current backward
   // weight-gradient kernels (MFMA-bound) run on a side stream, overlapping the HBM-bound dgrad -> GroupNorm-backward chain
+  bool fused_stats = true;
   hipStream_t side = nullptr, side2 = nullptr; std::vector<hipEvent_t> evs; size_t ev_next = 0; bool side_dirty = false; bool use_side = true;
 };
 
@@ -233,6 +238,10 @@ static int build_plan(pu_ctx* c) {
     b.x = xin; b.out = outa;
     const int oH = s.down ? inH / 2 : (s.up ? inH * 2 : inH), oW = s.down ? inW / 2 : (s.up ? inW * 2 : inW);
     const std::string& p = s.name;
+    if (conv_uses_frag_layout((int)esz, oH, oW)) {         // conv3-class producers: at least 64 pixels per wave
+      b.cap_out = oH * oW / 64; b.st_out = alloc_f32(c, (size_t)mb * b.cap_out * s.cout * 2);
+      if (s.is_block) { b.cap_c0 = b.cap_out; b.st_c0 = alloc_f32(c, (size_t)mb * b.cap_c0 * s.cout * 2); }
+    }
     if (!s.is_block) {
       const int64_t w = add_param(c, p + ".weight", {s.cout, s.cin, 3, 3});
       const int64_t bb = add_param(c, p + ".bias", {s.cout});
@@ -274,6 +283,7 @@ static int build_plan(pu_ctx* c) {
     Act cur = c->x_in; int curH = H, curW = W;
     for (size_t i = 0; i < es.size(); ++i) {
       build_block(es[i], c->enc[i], cur, enc_out[i], curH, curW);
+      c->enc[i].src0 = (int)i - 1;
       if (es[i].down) { curH /= 2; curW /= 2; }
       cur = enc_out[i];
     }
@@ -286,6 +296,8 @@ static int build_plan(pu_ctx* c) {
       if (j + 1 < ds.size() && ds[j + 1].concat) outa = view_act(cat[j + 1], 0, ds[j].cout, esz);
       else outa = alloc_act(c, mb, oH, oW, ds[j].cout);
       build_block(ds[j], c->dec[j], xin, outa, curH, curW);
+      c->dec[j].src0 = j == 0 ? (int)es.size() - 1 : 1000 + (int)j - 1;
+      if (ds[j].concat) c->dec[j].src1 = skip_of_dec[j];
       curH = oH; curW = oW; cur = outa;
     }
     // ---- output head (networks.py:296-297,331)
@@ -386,8 +398,11 @@ static int ensure_packed(pu_ctx* c, hipStream_t s) {
 }
 
 template <typename T>
-static int conv_fwd(pu_ctx* c, const ConvL& L, TV in, TV out, int B, bool relu, const TV* res, int accumulate, hipStream_t s) {
+static int conv_fwd(pu_ctx* c, const ConvL& L, TV in, TV out, int B, bool relu, const TV* res, int accumulate, hipStream_t s,
+                    float* stat = nullptr, int stat_cap = 0, int* stat_slots = nullptr) {
   ConvArgs a; memset(&a, 0, sizeof a);
+  if (stat_slots) *stat_slots = 0;
+  if (stat && c->fused_stats) { a.stat_out = stat; a.stat_cap = stat_cap; a.stat_slots = stat_slots; }
   a.in = in.p; a.in_ld = in.ld;
   a.Cin = in.C;                       // channels present in the tensor (>= L.cin; extra planes meet zero-padded weights)
   a.wpk = (char*)c->packed + (size_t)L.pk_fwd * c->esz; a.cin_pk = L.cin_pk; a.cout_pk = L.rows_fwd; a.taps = L.ks * L.ks;
@@ -482,9 +497,26 @@ static GNArgs gn_args(pu_ctx* c, const GNL& n, TV x, TV y, int B, int train, uin
   a.part = c->gn_part; a.stat = n.stat; a.coef = n.coef; a.nchunk = n.nchunk;
   return a;
 }
+struct StatSrc { const float* p0 = nullptr; int n0 = 0, c0 = 0; const float* p1 = nullptr; int n1 = 0; };
+static Block& blk(pu_ctx* c, int id) { return id >= 1000 ? c->dec[id - 1000] : c->enc[id]; }
+// statistics of a block's input, when every producer of x delivered them in this forward
+static StatSrc src_of_x(pu_ctx* c, const Block& b) {
+  StatSrc q;
+  if (b.src0 < 0) return q;
+  const Block& p0 = blk(c, b.src0);
+  if (!p0.st_out || p0.sl_out <= 0) return q;
+  if (b.src1 >= 0) {
+    const Block& p1 = blk(c, b.src1);
+    if (!p1.st_out || p1.sl_out <= 0) return q;
+    q.p1 = p1.st_out; q.n1 = p1.sl_out;
+  }
+  q.p0 = p0.st_out; q.n0 = p0.sl_out; q.c0 = p0.cout;
+  return q;
+}
 template <typename T>
-static int gn_fwd(pu_ctx* c, const GNL& n, TV x, TV y, int B, int train, uint64_t seed, hipStream_t s) {
+static int gn_fwd(pu_ctx* c, const GNL& n, TV x, TV y, int B, int train, uint64_t seed, hipStream_t s, const StatSrc* st = nullptr) {
   GNArgs a = gn_args(c, n, x, y, B, train, seed);
+  if (st && st->p0) { a.ps0 = st->p0; a.ns0 = st->n0; a.pc0 = st->c0; a.ps1 = st->p1; a.ns1 = st->n1; }
   CKH(launch_gn_fwd<T>(a, s));
   return PU_OK;
 }
@@ -506,24 +538,26 @@ static int gn_bwd(pu_ctx* c, const GNL& n, TV x, TV y, TV dy, TV dx, int accumul
 template <typename T>
 static int block_fwd(pu_ctx* c, Block& b, int B, int train, uint64_t seed, hipStream_t s) {
   int r;
-  if (!b.is_block) return conv_fwd<T>(c, b.conv0, b.x.v, b.out.v, B, false, nullptr, 0, s);
+  if (!b.is_block) return conv_fwd<T>(c, b.conv0, b.x.v, b.out.v, B, false, nullptr, 0, s, b.st_out, b.cap_out, &b.sl_out);
   // x = conv0(resample(silu(norm0(x))))            networks.py:168
-  if ((r = gn_fwd<T>(c, b.n0, b.x.v, b.a0.v, B, train, seed, s))) return r;
-  if ((r = conv_fwd<T>(c, b.conv0, b.a0.v, b.c0.v, B, false, nullptr, 0, s))) return r;
+  const StatSrc sx = src_of_x(c, b);
+  if ((r = gn_fwd<T>(c, b.n0, b.x.v, b.a0.v, B, train, seed, s, &sx))) return r;
+  if ((r = conv_fwd<T>(c, b.conv0, b.a0.v, b.c0.v, B, false, nullptr, 0, s, b.st_c0, b.cap_c0, &b.sl_c0))) return r;
   // x = silu(shift + norm1(x) * (scale + 1)); dropout   networks.py:170-177
-  if ((r = gn_fwd<T>(c, b.n1, b.c0.v, b.h1.v, B, train, seed, s))) return r;
-  // x = conv1(x) + skip(orig)                        networks.py:177-179
+  StatSrc sc; if (b.sl_c0 > 0) { sc.p0 = b.st_c0; sc.n0 = b.sl_c0; sc.c0 = b.cout; }
+  if ((r = gn_fwd<T>(c, b.n1, b.c0.v, b.h1.v, B, train, seed, s, &sc))) return r;
+  // x = conv1(x) + skip(orig)                        networks.py:177-179   (conv1 is always the final writer of `out`)
   if (b.skip == SK_CONV) {
     TV sin = b.x.v;
     if (b.up || b.down) { CKH(launch_resample<T>(with_b(b.x.v, B), with_b(b.skin.v, B), b.down ? RS_DOWN : RS_UP, s)); sin = b.skin.v; }
     if ((r = conv_fwd<T>(c, b.skipc, sin, b.out.v, B, false, nullptr, 0, s))) return r;
-    return conv_fwd<T>(c, b.conv1, b.h1.v, b.out.v, B, false, nullptr, 1, s);
+    return conv_fwd<T>(c, b.conv1, b.h1.v, b.out.v, B, false, nullptr, 1, s, b.st_out, b.cap_out, &b.sl_out);
   }
   if (b.skip == SK_RESAMPLE) {
     CKH(launch_resample<T>(with_b(b.x.v, B), with_b(b.skin.v, B), b.down ? RS_DOWN : RS_UP, s));
-    return conv_fwd<T>(c, b.conv1, b.h1.v, b.out.v, B, false, &b.skin.v, 0, s);
+    return conv_fwd<T>(c, b.conv1, b.h1.v, b.out.v, B, false, &b.skin.v, 0, s, b.st_out, b.cap_out, &b.sl_out);
   }
-  return conv_fwd<T>(c, b.conv1, b.h1.v, b.out.v, B, false, &b.x.v, 0, s);
+  return conv_fwd<T>(c, b.conv1, b.h1.v, b.out.v, B, false, &b.x.v, 0, s, b.st_out, b.cap_out, &b.sl_out);
 }
 
 template <typename T>
@@ -568,7 +602,8 @@ static int unet_forward(pu_ctx* c, int B, int train, uint64_t seed, hipStream_t 
   for (auto& b : c->enc) if ((r = block_fwd<T>(c, b, B, train, seed, s))) return r;
   for (auto& b : c->dec) if ((r = block_fwd<T>(c, b, B, train, seed, s))) return r;
   Act& last = c->dec.back().out;
-  if ((r = gn_fwd<T>(c, c->out_norm, last.v, c->out_a.v, B, train, seed, s))) return r;
+  StatSrc so; { const Block& lb = c->dec.back(); if (lb.st_out && lb.sl_out > 0) { so.p0 = lb.st_out; so.n0 = lb.sl_out; so.c0 = lb.cout; } }
+  if ((r = gn_fwd<T>(c, c->out_norm, last.v, c->out_a.v, B, train, seed, s, &so))) return r;
   if ((r = conv_fwd<T>(c, c->out_conv, c->out_a.v, c->feat.v, B, false, nullptr, 0, s))) return r;
   c->unet_B = B; c->unet_train = train; c->unet_seed = seed;
   return PU_OK;
@@ -673,6 +708,7 @@ int pu_create(const pu_config* cfg, int device, pu_ctx** out) {
     c->evs.resize(256);
     for (auto& e : c->evs) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { c->use_side = false; e = nullptr; }
   } else c->use_side = false;
+  if (getenv("PU_NO_FUSED_STATS") || c->dt == PU_F32) c->fused_stats = false;
   if (getenv("PU_NO_SIDE_STREAM") || c->dt == PU_F32) c->use_side = false;   // the fp32 parity path shares scratch (bias_part) and stays serial
   *out = c;
   return PU_OK;

@@ -295,6 +295,30 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs a) {
   }
 }
 
+// Fused GroupNorm statistics: lane l owns the 8-channel chunk (l & 3) of every pixel it stores; after a butterfly over the
+// 16 lanes of equal chunk, lanes 0..3 hold the wave's (sum, sum of squares) per channel and write one 64-byte row each.
+__device__ __forceinline__ void wave_stat_store(float* s1, float* s2, int l, float* dst, bool ok) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+#pragma unroll
+    for (int off = 4; off < 64; off <<= 1) { s1[e] += __shfl_xor(s1[e], off); s2[e] += __shfl_xor(s2[e], off); }
+  }
+  if (l < 4 && ok) {
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+      float4 o; o.x = s1[e]; o.y = s2[e]; o.z = s1[e + 1]; o.w = s2[e + 1];
+      reinterpret_cast<float4*>(dst)[e >> 1] = o;
+    }
+  }
+}
+
+// host side: report the slot count of the chosen tiling, or switch the statistics off when the buffer is too small
+static inline void stat_resolve(ConvArgs& a, int slots) {
+  if (!a.stat_out) return;
+  if (slots > a.stat_cap) { a.stat_out = nullptr; slots = 0; }
+  if (a.stat_slots) *a.stat_slots = slots;
+}
+
 // ------------------------------------------------------------------ conv3: cout-split waves, weights straight to registers
 // 16-bit only.  Block = 4 waves; wave (wm, wn) owns NTM 32-pixel columns x ONE 32-cout row tile, so its A (weight)
 // fragments are private: they are read from the fragment-major packed buffer with one fully coalesced 1-KiB load per
@@ -441,6 +465,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3_kernel(ConvArgs a) {
   }
   T* out = reinterpret_cast<T*>(a.out);
   const T* res = reinterpret_cast<const T*>(a.res);
+  float s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
 #pragma unroll
   for (int it = 0; it < NTM * 2; ++it) {
     const int i = it * 64 + l;                               // (pixel of the wave, 8-cout chunk)
@@ -466,8 +493,20 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3_kernel(ConvArgs a) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
       }
-      *reinterpret_cast<V16*>(out + pix * a.out_ld + co) = pack<T>(v);
+      const V16 pk = pack<T>(v);
+      *reinterpret_cast<V16*>(out + pix * a.out_ld + co) = pk;
+      if (a.stat_out) {                                      // statistics of the values as stored (rounded to T)
+        float w[8]; unpack<T>(pk, w);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s1[e] += w[e]; s2[e] += w[e] * w[e]; }
+      }
     }
+  }
+  if (a.stat_out) {
+    const int slots = tiles_x * tiles_y * WM;
+    const int slot = ((ty0 / TH) * tiles_x + tx0 / TW) * WM + wm;
+    const int co = ct * 32 + (l & 3) * 8;
+    wave_stat_store(s1, s2, l, a.stat_out + (((size_t)b * slots + slot) * a.Cout + co) * 2, co < a.Cout);
   }
 }
 
@@ -609,6 +648,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3p_kernel(ConvArgs a) {
           store4<T>(stage + (j * 32 + (l & 31)) * ERS + 8 * q + 4 * (l >> 5), v);
         }
       }
+      float s1[8], s2[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
 #pragma unroll
       for (int it = 0; it < NTM * 2; ++it) {
         const int i = it * 64 + l;
@@ -634,8 +676,20 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3p_kernel(ConvArgs a) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
           }
-          *reinterpret_cast<V16*>(out + pix * a.out_ld + co) = pack<T>(v);
+          const V16 pk = pack<T>(v);
+          *reinterpret_cast<V16*>(out + pix * a.out_ld + co) = pk;
+          if (a.stat_out) {
+            float w[8]; unpack<T>(pk, w);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { s1[e] += w[e]; s2[e] += w[e] * w[e]; }
+          }
         }
+      }
+      if (a.stat_out) {
+        const int slots = tiles_x * tiles_y * WM;
+        const int slot = ((ty0 / TH) * tiles_x + tx0 / TW) * WM + wm;
+        const int co = ct * 32 + (l & 3) * 8;
+        wave_stat_store(s1, s2, l, a.stat_out + (((size_t)b * slots + slot) * a.Cout + co) * 2, co < a.Cout);
       }
     }
     if (nxt < ntiles) lstore(cur ^ 1);
@@ -645,7 +699,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3p_kernel(ConvArgs a) {
 }
 
 template <typename T, int KS, int TH, int TW, int WM, int WN, int NCH>
-static hipError_t launch_conv3p_cfg(const ConvArgs& a, hipStream_t s) {
+static hipError_t launch_conv3p_cfg(const ConvArgs& a0, hipStream_t s) {
+  ConvArgs a = a0;
+  stat_resolve(a, (a.W / TW) * (a.H / TH) * WM);
   constexpr int TAPS = KS * KS, PADP = KS / 2;
   constexpr int IH = TH + 2 * PADP, IW = TW + 2 * PADP, KCP = KC + MM<T>::PAD, BN = 32 * WN;
   constexpr size_t lds = ((size_t)2 * NCH * IH * IW * KCP + (size_t)(TH * TW / (32 * WM)) * 32 * 40 * WM * WN) * sizeof(T);
@@ -686,7 +742,9 @@ static hipError_t launch_conv3p(const ConvArgs& a, hipStream_t s) {
 }
 
 template <typename T, int KS, int TH, int TW, int WM, int WN>
-static hipError_t launch_conv3_cfg(const ConvArgs& a, hipStream_t s) {
+static hipError_t launch_conv3_cfg(const ConvArgs& a0, hipStream_t s) {
+  ConvArgs a = a0;
+  stat_resolve(a, (a.W / TW) * (a.H / TH) * WM);
   constexpr int TAPS = KS * KS, PADP = KS / 2;
   constexpr int IH = TH + 2 * PADP, IW = TW + 2 * PADP, KCP = KC + MM<T>::PAD, BN = 32 * WN;
   (void)TAPS;
@@ -789,6 +847,7 @@ static hipError_t launch_ks(const ConvArgs& a, hipStream_t s) {
 
 template <typename T>
 hipError_t launch_conv(const ConvArgs& a, hipStream_t s) {
+  if (a.stat_slots) *a.stat_slots = 0;             // only the conv3 / conv3p launchers produce fused statistics
   if (a.frag_layout) {
     if (!conv_uses_frag_layout((int)sizeof(T), a.H, a.W)) return hipErrorInvalidValue;
     if (a.taps == 9) return launch_conv3<T, 3>(a, s);

@@ -127,18 +127,48 @@ template <typename T>
 __global__ __launch_bounds__(256) void gn_finalize_kernel(TV x, const float* __restrict__ part, int nchunk, int G, float eps,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           const float* __restrict__ scale, const float* __restrict__ shift,
-                                                          float* __restrict__ stat, float* __restrict__ coef) {
+                                                          float* __restrict__ stat, float* __restrict__ coef,
+                                                          const float* __restrict__ ps0, int ns0, int pc0,
+                                                          const float* __restrict__ ps1, int ns1) {
   __shared__ double cs[1024 * 2];      // per channel: mean_c, M2_c
+  __shared__ double red[256 * 2];
   __shared__ float gs[64];
   const int b = blockIdx.x, tid = threadIdx.x, C = x.C;
   const long HW = (long)x.H * x.W;
-  const T* x0 = reinterpret_cast<const T*>(x.p) + (long)b * HW * x.ld;      // first pixel of the sample = the shift
-  for (int c = tid; c < C; c += 256) {
-    double a = 0, q = 0;
-    for (int k = 0; k < nchunk; ++k) { const float* pp = part + (((long)b * nchunk + k) * C + c) * 2; a += pp[0]; q += pp[1]; }
-    const double n = (double)HW, sh = (double)ET<T>::ld(x0 + c);
-    cs[c * 2] = sh + a / n;                      // channel mean
-    cs[c * 2 + 1] = q - a * a / n;               // channel sum of squared deviations
+  if (ps0) {
+    // producer-fused statistics: unshifted (sum, sum of squares) rows, one per producing wave; `nl` threads share a channel
+    for (int src = 0; src < 2; ++src) {
+      const float* ps = src ? ps1 : ps0;
+      const int Cs = src ? C - pc0 : pc0, cb = src ? pc0 : 0, ns = src ? ns1 : ns0;
+      if (Cs <= 0) continue;
+      const int nl = Cs >= 256 ? 1 : 256 / Cs;
+      for (int c0 = 0; c0 < Cs; c0 += 256) {
+        const int c = nl > 1 ? tid % Cs : c0 + tid, lane = nl > 1 ? tid / Cs : 0;
+        double a = 0, q = 0;
+        if (c < Cs && lane < nl) {
+          const float2* pp = reinterpret_cast<const float2*>(ps) + ((long)b * ns + lane) * Cs + c;
+          for (int k = lane; k < ns; k += nl, pp += (long)nl * Cs) { const float2 v = *pp; a += v.x; q += v.y; }
+        }
+        red[tid * 2] = a; red[tid * 2 + 1] = q;
+        __syncthreads();
+        if (c < Cs && lane == 0) {
+          for (int j = 1; j < nl; ++j) { a += red[(j * Cs + c) * 2]; q += red[(j * Cs + c) * 2 + 1]; }
+          const double n = (double)HW;
+          cs[(cb + c) * 2] = a / n;
+          cs[(cb + c) * 2 + 1] = q - a * a / n;
+        }
+        __syncthreads();
+      }
+    }
+  } else {
+    const T* x0 = reinterpret_cast<const T*>(x.p) + (long)b * HW * x.ld;      // first pixel of the sample = the shift
+    for (int c = tid; c < C; c += 256) {
+      double a = 0, q = 0;
+      for (int k = 0; k < nchunk; ++k) { const float* pp = part + (((long)b * nchunk + k) * C + c) * 2; a += pp[0]; q += pp[1]; }
+      const double n = (double)HW, sh = (double)ET<T>::ld(x0 + c);
+      cs[c * 2] = sh + a / n;                      // channel mean
+      cs[c * 2 + 1] = q - a * a / n;               // channel sum of squared deviations
+    }
   }
   __syncthreads();
   const int cpg = C / G;
@@ -258,9 +288,10 @@ hipError_t launch_gn_fwd(const GNArgs& a0, hipStream_t s) {
   for (int b0 = 0; b0 < a0.x.B; b0 += step) {
     const int nb = min(step, a0.x.B - b0);
     const GNArgs a = gn_sub(a0, b0, nb, sizeof(T));
-    hipLaunchKernelGGL((chan_partial_kernel<T, true>), dim3(a.nchunk, a.x.B), dim3(256), 0, s, a.x, a.part, a.nchunk, 1);
+    const bool fused = a.ps0 && a.ns0 > 0 && (a.pc0 >= a.x.C || (a.ps1 && a.ns1 > 0)) && step == a0.x.B;
+    if (!fused) hipLaunchKernelGGL((chan_partial_kernel<T, true>), dim3(a.nchunk, a.x.B), dim3(256), 0, s, a.x, a.part, a.nchunk, 1);
     hipLaunchKernelGGL(gn_finalize_kernel<T>, dim3(a.x.B), dim3(256), 0, s, a.x, a.part, a.nchunk, a.G, a.eps, a.gamma, a.beta,
-                       a.scale, a.shift, a.stat, a.coef);
+                       a.scale, a.shift, a.stat, a.coef, fused ? a.ps0 : nullptr, a.ns0, a.pc0, a.ps1, a.ns1);
     (void)HW;
     const dim3 ga(gn_pix_blocks((long)a.y.H * a.y.W, a.x.C / ET<T>::VEC, a.x.B), a.x.B);
     if (a.resample == RS_NONE) hipLaunchKernelGGL((gn_apply_kernel<T, RS_NONE>), ga, dim3(256), 0, s, a);

@@ -14,6 +14,11 @@ struct ConvArgs {
   int B, H, W;
   int relu; int accumulate;
   int frag_layout;                               // 1: wpk is fragment-major (conv3 kernel), see conv_uses_frag_layout()
+  // Fused GroupNorm statistics of the OUTPUT (optional): each wave adds the (sum, sum of squares) of the values it stores
+  // into its own row  stat_out[((b * slots + slot) * Cout + c) * 2 + {0,1}]  (written, never accumulated -> deterministic).
+  // The launcher reports the slot count per image of the tiling it chose through *stat_slots (host pointer; 0 = this
+  // kernel configuration does not produce statistics, the consumer then falls back to its own statistics pass).
+  float* stat_out; int stat_cap; int* stat_slots;
 };
 // 16-bit convolutions on >= 16-pixel-wide levels run the cout-split kernel whose weights are packed fragment-major:
 //   [cout tile of 32][32-channel chunk][tap][k-step][lane 0..63][8]  =  W[32 ct + (lane & 31)][tap][32 c + 16 kk + 8 (lane >> 5) + e]
@@ -57,6 +62,9 @@ struct GNArgs {
   float drop_p; uint64_t drop_seed; uint32_t drop_stream;   // drop_p == 0 -> no dropout
   // workspaces (fp32): part [B][nchunk][C][2], stat [B][G][2] (mean, rstd), coef [B][C][4] (A, Bp, mean, rstd; 16-byte aligned)
   float* part; float* stat; float* coef; int nchunk;
+  // producer-fused statistics (see ConvArgs::stat_out): channels [0, pc0) from ps0 (ns0 slots per image), the rest from ps1;
+  // ps0 == null -> the statistics pass runs here
+  const float* ps0; int ns0; int pc0; const float* ps1; int ns1;
   int b0;                     // batch offset of this launch inside the tensor (batch-chunked launches; keeps the dropout index global)
 };
 template <typename T> hipError_t launch_gn_fwd(const GNArgs&, hipStream_t);
