@@ -38,7 +38,7 @@ typedef enum {
 
 typedef enum { PU_F32 = 0, PU_F16 = 1, PU_BF16 = 2 } pu_dtype;
 typedef enum { PU_PRIOR = 0, PU_POSTERIOR = 1 } pu_net;
-typedef enum { PU_RECON_AFCRPS = 0, PU_RECON_L1 = 1 } pu_recon;
+typedef enum { PU_RECON_AFCRPS = 0, PU_RECON_L1 = 1, PU_RECON_WMSE_MSSSIM = 2 } pu_recon;
 
 #define PU_MAX_LEVELS 8
 
@@ -71,7 +71,7 @@ typedef struct {
 } pu_param_desc;
 
 /* Scalars written by pu_elbo_fwd_bwd (device array of PU_NUM_SCALARS floats). */
-enum { PU_S_TOTAL = 0, PU_S_RECON = 1, PU_S_KL_MEAN = 2, PU_S_KL2_MEAN = 3, PU_NUM_SCALARS = 8 };
+enum { PU_S_TOTAL = 0, PU_S_RECON = 1, PU_S_KL_MEAN = 2, PU_S_KL2_MEAN = 3, PU_S_WMSE = 4, PU_S_MSSSIM = 5, PU_NUM_SCALARS = 8 };
 
 /* ---- lifetime (replaces ProbabilisticUNet.__init__, prob_unet.py:146-189) ------------------------------- */
 int pu_create(const pu_config* cfg, int device, pu_ctx** out);
@@ -120,6 +120,32 @@ int pu_elbo_fwd_bwd(pu_ctx*, const float* x, const float* target, const float* e
 int pu_sample(pu_ctx*, const float* x, const float* target_or_null, const float* eps, int B, int n,
               float* out, float* mu, float* sigma, void* stream);
 
+/* Same, with ClimExDataset.residual_to_hr (climex_utils.py:277-285; applied per sample on the host in
+ * train_prob_unet_model.py:246, latent_exploration.py:142) fused into the Fcomb store:
+ *   out[b,s,c,:,:] = lrinterp[b,c,:,:] + residual * (resid_std[c,:,:] + epsilon),
+ * optionally followed by climex_utils.softplus (:41-45; value > 20 ? value : log(exp(value) + 1) - softplus_c). */
+int pu_sample_hr(pu_ctx*, const float* x, const float* target_or_null, const float* eps, int B, int n,
+                 const float* lrinterp, const float* resid_std, float epsilon, int softplus, float softplus_c,
+                 float* out, float* mu, float* sigma, void* stream);
+
+/* ---- WMSE-MS-SSIM reconstruction term (the live `elbo`, prob_unet.py:229-267; wmse_ms_ssim_loss, prob_unet_utils.py:270-305):
+ *      parameters used by pu_elbo_fwd_bwd(recon_kind = PU_RECON_WMSE_MSSSIM).  data_range <= 0: inferred on the device as
+ *      max(target) - min(target) clamped at 1e-5 (prob_unet_utils.py:288-289; under data parallelism pass a fixed value).
+ *      Scalars: PU_S_RECON = mean over the M members of lam * WMSE + (1 - lam) * (1 - MS-SSIM); PU_S_WMSE / PU_S_MSSSIM =
+ *      the LAST member's WMSE and (1 - MS-SSIM), which is what the reference returns for logging.  Requires H, W > 96.
+ *      MS-SSIM restates pytorch-msssim 1.0.0 (absent from this image): parity unpinned, see oracle/probunet_oracle.py. */
+int pu_set_recon_wmse_msssim(pu_ctx*, float alpha_w, float beta_w, float lam_w, float data_range);
+
+/* ---- ClimEx-shaped data transforms on the device (climex_utils.py:197-225, :255-264); all pointers device fp32 NCHW ----
+ * pu_lr_stats: mean / unbiased std over the N items of the k x k block means (AvgPool2d(k)); *_lr are [C,H/k,W/k],
+ *   *_hr their repeat_interleave expansion [C,H,W] (any output may be null).
+ * pu_lrinterp_to_residuals: lr = AvgPool2d(k)(hr); lrinterp = nearest upsample; inputs = (lrinterp - mean)/(std + epsilon);
+ *   targets = (hr - mean)/(std + epsilon) - inputs.  lrinterp [B,C,H,W] and lr [B,C,H/k,W/k] are optional outputs. */
+int pu_lr_stats(const float* hr, int N, int C, int H, int W, int k, float* mean_lr, float* std_lr, float* mean_hr, float* std_hr,
+                void* stream);
+int pu_lrinterp_to_residuals(const float* hr, int B, int C, int H, int W, int k, const float* mean_hr, const float* std_hr,
+                             float epsilon, float* inputs, float* targets, float* lrinterp, float* lr, void* stream);
+
 /* ---- optimizer (replaces torch.optim.AdamW(model.parameters(), lr=1e-4).step(), main.py:103, train_prob_unet_model.py:141) on
  *      the flat buffers: one fused pass; exp_avg / exp_avg_sq are caller-owned fp32 arrays of n elements; step counts from 1. */
 int pu_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
@@ -154,6 +180,12 @@ int pu_op_gnsilu(int dtype, int resample, int B, int C, int H, int W, const floa
                  const float* beta, const float* scale_shift_or_null, float* y,
                  const float* dy_or_null, float* dx, float* dgamma, float* dbeta, float* dscale_shift,
                  float drop_p, uint64_t drop_seed, void* stream);
+
+/* WMSE-MS-SSIM loss and its gradient on fp32 device tensors pred [B,M,C,H,W], target [B,C,H,W] (stand-alone test hook for
+ * the kernels behind PU_RECON_WMSE_MSSSIM). out_scalars: PU_NUM_SCALARS floats (PU_S_RECON, PU_S_WMSE, PU_S_MSSSIM filled);
+ * dpred (nullable) receives gscale * d(recon)/d(pred). Syncs. */
+int pu_op_wmse_msssim(const float* pred, const float* target, int B, int M, int C, int H, int W, float alpha_w, float beta_w,
+                      float lam_w, float data_range, float gscale, float* out_scalars, float* dpred, void* stream);
 
 #ifdef __cplusplus
 }

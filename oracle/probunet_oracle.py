@@ -30,9 +30,21 @@ captured from the *imported reference*, see tools/make_golden.py):
   * posterior stem generalised to (Cin + Cout) input planes; for Cout == Cin identical to the
     reference, for Cout < Cin identical to the reference fed a zero-padded target.
 
-Parity status: PINNED by golden vectors generated from the reference import (no denial encountered).
-The MS-SSIM half of the live WMSE-MS-SSIM elbo (prob_unet.py:229-267) needs pytorch-msssim 1.0.0
-(uv.lock:786-794), which is absent offline: that variant is "parity unpinned" and not implemented here.
+  src/prob_unet.py:229-267 elbo, live WMSE-MS-SSIM variant          -> elbo(recon="wmse_msssim")
+  src/prob_unet_utils.py:270-305 wmse_ms_ssim_loss                  -> wmse_ms_ssim_loss
+  src/climex_utils.py:36-46,197-225,255-285 data transforms         -> softplus_climex, lrinterp_to_residuals, lr_stats, residual_to_hr
+
+Parity status: PINNED by golden vectors generated from the reference import (no denial encountered), with ONE exception:
+  ms_ssim() below restates the third-party dependency `pytorch-msssim==1.0.0` (pinned in uv.lock:786-794, imported at
+  prob_unet_utils.py:8, called at :297 with win_size=7, size_average=True).  The package is absent from this image and cannot
+  be installed (no network), and the reference holds no test or golden value for it: the MS-SSIM arithmetic is
+  **PARITY UNPINNED** — restated from the package's published algorithm (Wang et al. 2003 as implemented by pytorch-msssim:
+  5 scales, weights (0.0448, 0.2856, 0.3001, 0.2363, 0.1333), K = (0.01, 0.03), Gaussian window sigma 1.5 applied separably with
+  no padding, relu on the per-scale means, 2x2 average pooling with padding = size % 2).  Everything around it — the WMSE half,
+  the lam-combination, the data_range inference, the ensemble-mean rule — IS pinned (tests/golden/wmse.json, captured from the
+  imported reference with ms_ssim replaced by a recording constant).
+  The climex_utils transforms are four torch calls each (AvgPool2d, interpolate, mean/std, arithmetic); climex_utils itself
+  cannot be imported here (xarray absent), so they are restated from the source text and checked against those torch calls.
 """
 from __future__ import annotations
 
@@ -343,9 +355,107 @@ def l1_recon(pred: Tensor, target: Tensor) -> Tensor:
 
 
 # ----------------------------------------------------------------------------- model-level entry points
+# ---------------------------------------------------------------------------- WMSE-MS-SSIM (prob_unet_utils.py:270-305)
+MS_SSIM_WEIGHTS = (0.0448, 0.2856, 0.3001, 0.2363, 0.1333)
+
+
+def gauss_window(size: int = 7, sigma: float = 1.5) -> Tensor:
+    """pytorch-msssim `_fspecial_gauss_1d`: exp(-(i - size//2)^2 / (2 sigma^2)), normalised, fp32."""
+    c = torch.arange(size, dtype=torch.float32) - size // 2
+    g = torch.exp(-(c ** 2) / (2 * sigma ** 2))
+    return g / g.sum()
+
+
+def gaussian_filter(x: Tensor, win: Tensor) -> Tensor:
+    """Separable depthwise 'valid' filtering (rows, then columns), as pytorch-msssim `gaussian_filter`."""
+    C = x.shape[1]
+    k = win.numel()
+    x = F.conv2d(x, win.view(1, 1, k, 1).repeat(C, 1, 1, 1), groups=C)
+    return F.conv2d(x, win.view(1, 1, 1, k).repeat(C, 1, 1, 1), groups=C)
+
+
+def ssim_maps(X: Tensor, Y: Tensor, win: Tensor, data_range: float):
+    """pytorch-msssim `_ssim`: per-(image, channel) spatial means of the ssim map and of the cs map."""
+    C1, C2 = (0.01 * data_range) ** 2, (0.03 * data_range) ** 2
+    mu1, mu2 = gaussian_filter(X, win), gaussian_filter(Y, win)
+    mu1_sq, mu2_sq, mu12 = mu1 * mu1, mu2 * mu2, mu1 * mu2
+    s1 = gaussian_filter(X * X, win) - mu1_sq
+    s2 = gaussian_filter(Y * Y, win) - mu2_sq
+    s12 = gaussian_filter(X * Y, win) - mu12
+    cs_map = (2 * s12 + C2) / (s1 + s2 + C2)
+    ssim_map = ((2 * mu12 + C1) / (mu1_sq + mu2_sq + C1)) * cs_map
+    return ssim_map.flatten(2).mean(-1), cs_map.flatten(2).mean(-1)
+
+
+def ms_ssim(X: Tensor, Y: Tensor, data_range: float, win_size: int = 7, win_sigma: float = 1.5, size_average: bool = True) -> Tensor:
+    """pytorch-msssim 1.0.0 `ms_ssim` (PARITY UNPINNED, see the module header)."""
+    if min(X.shape[-2:]) <= (win_size - 1) * 2 ** 4:
+        raise AssertionError("Image size should be larger than %d due to the 4 downsamplings in ms-ssim" % ((win_size - 1) * 2 ** 4))
+    win = gauss_window(win_size, win_sigma).to(X.dtype)
+    w = torch.tensor(MS_SSIM_WEIGHTS, dtype=X.dtype)
+    mcs = []
+    for i in range(5):
+        ssim_pc, cs = ssim_maps(X, Y, win, data_range)
+        if i < 4:
+            mcs.append(torch.relu(cs))
+            pad = [s % 2 for s in X.shape[2:]]
+            X = F.avg_pool2d(X, kernel_size=2, padding=pad)
+            Y = F.avg_pool2d(Y, kernel_size=2, padding=pad)
+    stack = torch.stack(mcs + [torch.relu(ssim_pc)], dim=0)          # [level, image, channel]
+    val = torch.prod(stack ** w.view(-1, 1, 1), dim=0)
+    return val.mean() if size_average else val.mean(1)
+
+
+def wmse_ms_ssim_loss(pred: Tensor, target: Tensor, alpha: float = 0.007, beta: float = 0.048, lam: float = 0.0,
+                      data_range: Optional[float] = None, ms_ssim_fn=None):
+    """prob_unet_utils.py:270-305.  Returns (combined, wmse, 1 - ms_ssim).  `ms_ssim_fn` lets a test substitute the
+    third-party call the way tools/make_golden.py did when it captured tests/golden/wmse.json."""
+    if pred.dim() == 5:
+        pred = pred.mean(1)
+    if data_range is None:
+        data_range = float((target.max() - target.min()).clamp(min=1e-5))
+    weights = torch.clamp(alpha * torch.exp(beta * target), max=1.0)
+    wmse = (weights * (pred - target).pow(2)).mean()
+    msv = (ms_ssim_fn or ms_ssim)(pred, target, data_range=data_range, win_size=7, size_average=True)
+    msl = 1.0 - msv
+    return lam * wmse + (1.0 - lam) * msl, wmse, msl
+
+
+# ---------------------------------------------------------------------------- ClimEx data transforms (climex_utils.py)
+def softplus_climex(d: Tensor, threshold: float = 20.0, c: float = 1e-7) -> Tensor:
+    """climex_utils.py:41-45 (out of place)."""
+    return torch.where(d > threshold, d, torch.log(torch.exp(d) + 1.0) - c)
+
+
+def lr_stats(hr: Tensor, k: int):
+    """climex_utils.py:255-264 compute_stats: hr [N,C,H,W] -> (mean_lr, std_lr), (mean_hr, std_hr)."""
+    lr = F.avg_pool2d(hr, k)
+    mean, std = lr.mean(dim=0), lr.std(dim=0)
+    rep = lambda t: t.repeat_interleave(k, dim=1).repeat_interleave(k, dim=2)
+    return (mean, std), (rep(mean), rep(std))
+
+
+def lrinterp_to_residuals(hr: Tensor, k: int, mean_hr: Tensor, std_hr: Tensor, epsilon: float = 1e-10):
+    """climex_utils.py:197-225 item transform, batched: hr [B,C,H,W] -> dict(inputs, targets, lrinterp, lr)."""
+    lr = F.avg_pool2d(hr, k)
+    lrinterp = F.interpolate(lr, scale_factor=k)                     # nearest
+    li = (lrinterp - mean_hr) / (std_hr + epsilon)
+    hs = (hr - mean_hr) / (std_hr + epsilon)
+    return dict(inputs=li, targets=hs - li, lrinterp=lrinterp, lr=lr)
+
+
+def residual_to_hr(residual: Tensor, lrinterp: Tensor, std_hr: Tensor, epsilon: float = 1e-10) -> Tensor:
+    """climex_utils.py:270-285 for the residual dataset types: lrinterp + residual * (std + eps).
+    residual [B,n,C,H,W] or [B,C,H,W]; lrinterp [B,C,H,W]; std_hr [C,H,W]."""
+    if residual.dim() == 5:
+        return lrinterp.unsqueeze(1) + residual * (std_hr + epsilon)
+    return lrinterp + residual * (std_hr + epsilon)
+
+
 def elbo(P: Params, cfg: Config, x: Tensor, target: Tensor, eps: Tensor,
          beta0: float, beta1: float, beta2: float = 0.0, alpha: float = 0.95, recon: str = "afcrps",
-         drop_masks: Optional[Dict[str, Tensor]] = None):
+         drop_masks: Optional[Dict[str, Tensor]] = None, alpha_w: float = 0.007, beta_w: float = 0.048, lam_w: float = 0.0,
+         data_range: Optional[float] = None):
     """afCRPS ELBO (prob_unet.py:273-317) or L1 ELBO (:325-381) with explicit noise eps [M,B,L].
     Returns dict(total, recon, kl[B], kl2[B], feat, mu_p, ls_p, mu_q, ls_q, preds[B,M,C,H,W])."""
     feat = unet_forward(P, cfg, x, drop_masks)
@@ -360,6 +470,10 @@ def elbo(P: Params, cfg: Config, x: Tensor, target: Tensor, eps: Tensor,
         rec = afcrps(preds, target, alpha)
     elif recon == "l1":
         rec = l1_recon(preds[:, 0], target)
+    elif recon == "wmse_msssim":                                     # prob_unet.py:244-252: per-member loss, averaged
+        parts = [wmse_ms_ssim_loss(preds[:, m], target, alpha_w, beta_w, lam_w, data_range) for m in range(M)]
+        rec = torch.stack([p[0] for p in parts]).mean()
+        extra = dict(wmse=parts[-1][1], msssim=parts[-1][2])         # the reference returns the LAST member's components
     else:
         raise ValueError(recon)
     kl = kl_diag_normal(mu_q, sq, mu_p, sp)
@@ -367,8 +481,11 @@ def elbo(P: Params, cfg: Config, x: Tensor, target: Tensor, eps: Tensor,
     total = beta0 * rec + beta1 * kl.mean()
     if recon == "l1":
         total = total + beta2 * kl2.mean()
-    return dict(total=total, recon=rec, kl=kl, kl2=kl2, feat=feat, mu_p=mu_p, ls_p=ls_p,
-                mu_q=mu_q, ls_q=ls_q, preds=preds)
+    out = dict(total=total, recon=rec, kl=kl, kl2=kl2, feat=feat, mu_p=mu_p, ls_p=ls_p,
+               mu_q=mu_q, ls_q=ls_q, preds=preds)
+    if recon == "wmse_msssim":
+        out.update(extra)
+    return out
 
 
 def sample_forward(P: Params, cfg: Config, x: Tensor, eps: Tensor, target: Optional[Tensor] = None):

@@ -3,3 +3,4 @@ ProbabilisticUNet interface.  Compute lives in libprobunet.so (HIP, gfx950); thi
 from . import _lib  # noqa: F401
 from .prob_unet import ProbabilisticUNet, FlatAdamW  # noqa: F401,E402
 from . import dp  # noqa: F401,E402
+from . import trainer, data  # noqa: F401,E402

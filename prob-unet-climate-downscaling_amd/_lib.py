@@ -8,8 +8,8 @@ LIB_PATH = os.path.join(_HERE, "libprobunet.so")
 PU_MAX_LEVELS = 8
 PU_F32, PU_F16, PU_BF16 = 0, 1, 2
 PU_PRIOR, PU_POSTERIOR = 0, 1
-PU_RECON_AFCRPS, PU_RECON_L1 = 0, 1
-PU_S_TOTAL, PU_S_RECON, PU_S_KL_MEAN, PU_S_KL2_MEAN, PU_NUM_SCALARS = 0, 1, 2, 3, 8
+PU_RECON_AFCRPS, PU_RECON_L1, PU_RECON_WMSE_MSSSIM = 0, 1, 2
+PU_S_TOTAL, PU_S_RECON, PU_S_KL_MEAN, PU_S_KL2_MEAN, PU_S_WMSE, PU_S_MSSSIM, PU_NUM_SCALARS = 0, 1, 2, 3, 4, 5, 8
 DTYPES = {"f32": PU_F32, "fp32": PU_F32, "float32": PU_F32, "f16": PU_F16, "fp16": PU_F16, "float16": PU_F16,
           "bf16": PU_BF16, "bfloat16": PU_BF16}
 
@@ -69,6 +69,14 @@ def lib():
     L.pu_elbo_fwd_bwd.restype = i32
     L.pu_elbo_fwd_bwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, f32, f32, f32, f32, i32, u64, i32, vp, vp, vp, vp]
     L.pu_sample.restype = i32; L.pu_sample.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp]
+    L.pu_sample_hr.restype = i32
+    L.pu_sample_hr.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, f32, i32, f32, vp, vp, vp, vp]
+    L.pu_set_recon_wmse_msssim.restype = i32; L.pu_set_recon_wmse_msssim.argtypes = [vp, f32, f32, f32, f32]
+    L.pu_lr_stats.restype = i32; L.pu_lr_stats.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]
+    L.pu_lrinterp_to_residuals.restype = i32
+    L.pu_lrinterp_to_residuals.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, f32, vp, vp, vp, vp, vp]
+    L.pu_op_wmse_msssim.restype = i32
+    L.pu_op_wmse_msssim.argtypes = [vp, vp, i32, i32, i32, i32, i32, f32, f32, f32, f32, f32, vp, vp, vp]
     L.pu_elbo_fwd_flops.restype = C.c_double; L.pu_elbo_fwd_flops.argtypes = [vp, i32, i32]
     L.pu_profile_enable.restype = i32; L.pu_profile_enable.argtypes = [i32]
     L.pu_adamw_step.restype = i32

@@ -80,6 +80,8 @@ struct pu_ctx {
   float inv_scale = 1.f;            // 1 / (loss scale) applied to every parameter-gradient write of the current backward
   // weight-gradient kernels (MFMA-bound) run on a side stream, overlapping the HBM-bound dgrad -> GroupNorm-backward chain
   bool fused_stats = true;
+  float wm_alpha = 0.007f, wm_beta = 0.048f, wm_lam = 0.f, wm_range = -1.f;     // wmse_ms_ssim_loss defaults (prob_unet.py:231-233)
+  float* ms_ws = nullptr; size_t ms_ws_floats = 0;                              // MS-SSIM pyramid workspace, allocated on first use
   hipStream_t side = nullptr, side2 = nullptr; std::vector<hipEvent_t> evs; size_t ev_next = 0; bool side_dirty = false; bool use_side = true;
 };
 
@@ -719,6 +721,7 @@ int pu_destroy(pu_ctx* c) {
   for (auto e : c->evs) if (e) (void)hipEventDestroy(e);
   if (c->side) (void)hipStreamDestroy(c->side);
   if (c->side2) (void)hipStreamDestroy(c->side2);
+  if (c->ms_ws) (void)hipFree(c->ms_ws);
   if (c->arena) (void)(void)hipFree(c->arena);
   if (c->packed) (void)(void)hipFree(c->packed);
   if (c->descs_dev) (void)(void)hipFree(c->descs_dev);
@@ -895,7 +898,15 @@ int pu_elbo_fwd_bwd(pu_ctx* c, const float* x, const float* target, const float*
   if (M < 1 || M > c->cfg.max_members) FAIL(PU_ERR_INVALID, "M=%d outside [1, max_members=%d]", M, c->cfg.max_members);
   if (recon_kind == PU_RECON_AFCRPS && M < 2) FAIL(PU_ERR_INVALID, "M must be at least 2 to compute afCRPS but got M=%d", M);
   if (recon_kind == PU_RECON_AFCRPS && M > 16) FAIL(PU_ERR_INVALID, "M=%d > 16 unsupported by the fused afCRPS kernel", M);
-  if (recon_kind != PU_RECON_AFCRPS && recon_kind != PU_RECON_L1) FAIL(PU_ERR_INVALID, "unknown recon kind %d", recon_kind);
+  if (recon_kind != PU_RECON_AFCRPS && recon_kind != PU_RECON_L1 && recon_kind != PU_RECON_WMSE_MSSSIM) FAIL(PU_ERR_INVALID, "unknown recon kind %d", recon_kind);
+  const bool msssim = recon_kind == PU_RECON_WMSE_MSSSIM;
+  if (msssim) {
+    if (c->cfg.H <= 96 || c->cfg.W <= 96) FAIL(PU_ERR_INVALID, "Image size should be larger than 96 due to the 4 downsamplings in ms-ssim (got %dx%d)", c->cfg.H, c->cfg.W);
+    if (!c->ms_ws) {
+      c->ms_ws_floats = msssim_ws_floats(c->cfg.max_batch, c->cfg.max_members, c->cfg.num_classes, c->cfg.H, c->cfg.W);
+      if (hipMalloc(&c->ms_ws, c->ms_ws_floats * sizeof(float)) != hipSuccess) { c->ms_ws = nullptr; FAIL(PU_ERR_NOMEM, "hipMalloc(MS-SSIM workspace, %zu bytes)", c->ms_ws_floats * sizeof(float)); }
+    }
+  }
   if (with_backward && !c->grads) FAIL(PU_ERR_STATE, "no gradient buffer bound");
   hipStream_t s = (hipStream_t)stream;
   if ((r = ensure_packed(c, s))) return r;
@@ -907,7 +918,8 @@ int pu_elbo_fwd_bwd(pu_ctx* c, const float* x, const float* target, const float*
   float S = cf.grad_scale > 0.f ? cf.grad_scale : 1.f;
   if (cf.grad_scale <= 0.f && c->dt == PU_F16) {
     const double norm = l1 ? 1.0 / ((double)B * Co * HW) : 1.0 / ((double)B * M * (M - 1) * Co * HW);
-    const double want = 1.0 / (2.0 * fmax(fabs((double)beta0), 1e-6) * norm * (l1 ? 1.0 : (double)(M - 1)));
+    double want = 1.0 / (2.0 * fmax(fabs((double)beta0), 1e-6) * norm * (l1 ? 1.0 : (double)(M - 1)));
+    if (msssim) want = 1.0 / (32.0 * fmax(fabs((double)beta0), 1e-6)) * (double)B * M * Co * HW;   // SSIM gradients: ~16x the L1 headroom
     int e2 = (int)floor(log2(fmax(want, 1.0))); if (e2 > 24) e2 = 24;
     S = (float)ldexp(1.0, e2);
   }
@@ -932,6 +944,13 @@ int pu_elbo_fwd_bwd(pu_ctx* c, const float* x, const float* target, const float*
     CKH(launch_latent_fwd(la, s));
     FcombArgs fa = fcomb_args(c, with_b(c->feat.v, B), 0, c->z, B, Mf, c->preds);
     CKH(launch_fcomb_fwd<T>(fa, s));
+    if (msssim) {
+      MsssimArgs ma; memset(&ma, 0, sizeof ma);
+      ma.pred = c->preds; ma.target = target; ma.B = B; ma.M = Mf; ma.C = Co; ma.H = cf.H; ma.W = cf.W;
+      ma.alpha_w = c->wm_alpha; ma.beta_w = c->wm_beta; ma.lam_w = c->wm_lam; ma.data_range = c->wm_range; ma.gscale = beta0 * S;
+      ma.ws = c->ms_ws; ma.ws_floats = c->ms_ws_floats; ma.scalars = c->scal; ma.dpred = with_backward ? c->dpreds : nullptr;
+      CKH(launch_wmse_msssim(ma, s));
+    } else
     CKH(launch_recon(recon_kind, c->preds, target, with_backward ? c->dpreds : nullptr, c->scal, B, Mf, Co, HW, alpha, beta0 * S, s));
     CKH(launch_finish_scalars(c->scal, beta0, beta1, beta2, l1 ? 1 : 0, s));
     if (out_scalars) CKH(hipMemcpyAsync(out_scalars, c->scal, PU_NUM_SCALARS * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -963,7 +982,8 @@ __global__ void export_mu_sigma_kernel(const float* mu, const float* ls, float* 
   if (i < n) { if (omu) omu[i] = mu[i]; if (osig) osig[i] = expf(ls[i]) + 1e-7f; }
 }
 
-int pu_sample(pu_ctx* c, const float* x, const float* target, const float* eps, int B, int n, float* out, float* mu, float* sigma, void* stream) {
+static int sample_impl(pu_ctx* c, const float* x, const float* target, const float* eps, int B, int n, float* out, float* mu, float* sigma,
+                       const float* lrinterp, const float* resid_std, float epsilon, int softplus, float softplus_c, void* stream) {
   if (!c || !x || !eps || !out) return PU_ERR_INVALID;
   int r; if ((r = check_B(c, B))) return r;
   if (n < 1 || n > c->cfg.max_members) FAIL(PU_ERR_INVALID, "n=%d outside [1, max_members=%d]", n, c->cfg.max_members);
@@ -983,10 +1003,50 @@ int pu_sample(pu_ctx* c, const float* x, const float* target, const float* eps, 
     la.mu_q = g.mu; la.ls_q = g.ls; la.eps = eps; la.z = c->z; la.B = B; la.L = L; la.M = n;
     CKH(launch_latent_fwd(la, s));
     FcombArgs fa = fcomb_args(c, with_b(c->feat.v, B), 0, c->z, B, n, out);
+    fa.hr_base = lrinterp; fa.hr_std = resid_std; fa.hr_eps = epsilon; fa.hr_softplus = softplus; fa.hr_softplus_c = softplus_c;
     CKH(launch_fcomb_fwd<T>(fa, s));
     if (mu || sigma) hipLaunchKernelGGL(export_mu_sigma_kernel, dim3(cdiv((long)B * L, 256)), dim3(256), 0, s, g.mu, g.ls, mu, sigma, B * L);
     return PU_OK;
   });
+}
+int pu_set_recon_wmse_msssim(pu_ctx* c, float alpha_w, float beta_w, float lam_w, float data_range) {
+  if (!c) return PU_ERR_INVALID;
+  c->wm_alpha = alpha_w; c->wm_beta = beta_w; c->wm_lam = lam_w; c->wm_range = data_range;
+  return PU_OK;
+}
+int pu_lr_stats(const float* hr, int N, int C, int H, int W, int k, float* mean_lr, float* std_lr, float* mean_hr, float* std_hr, void* stream) {
+  if (!hr || N < 1 || C < 1 || k < 1 || H % k || W % k) return PU_ERR_INVALID;
+  return launch_lr_stats(hr, N, C, H, W, k, mean_lr, std_lr, mean_hr, std_hr, (hipStream_t)stream) == hipSuccess ? PU_OK : PU_ERR_HIP;
+}
+int pu_lrinterp_to_residuals(const float* hr, int B, int C, int H, int W, int k, const float* mean_hr, const float* std_hr, float epsilon,
+                             float* inputs, float* targets, float* lrinterp, float* lr, void* stream) {
+  if (!hr || !mean_hr || !std_hr || !inputs || !targets || B < 1 || C < 1 || k < 1 || H % k || W % k) return PU_ERR_INVALID;
+  return launch_lrinterp_residuals(hr, B, C, H, W, k, mean_hr, std_hr, epsilon, inputs, targets, lrinterp, lr, (hipStream_t)stream) == hipSuccess
+             ? PU_OK : PU_ERR_HIP;
+}
+int pu_op_wmse_msssim(const float* pred, const float* target, int B, int M, int C, int H, int W, float alpha_w, float beta_w, float lam_w,
+                      float data_range, float gscale, float* out_scalars, float* dpred, void* stream) {
+  if (!pred || !target || !out_scalars || B < 1 || M < 1 || C < 1 || H <= 96 || W <= 96) return PU_ERR_INVALID;
+  hipStream_t s = (hipStream_t)stream;
+  MsssimArgs ma; memset(&ma, 0, sizeof ma);
+  ma.pred = pred; ma.target = target; ma.B = B; ma.M = M; ma.C = C; ma.H = H; ma.W = W;
+  ma.alpha_w = alpha_w; ma.beta_w = beta_w; ma.lam_w = lam_w; ma.data_range = data_range; ma.gscale = gscale;
+  ma.ws_floats = msssim_ws_floats(B, M, C, H, W); ma.scalars = out_scalars; ma.dpred = dpred;
+  if (hipMalloc(&ma.ws, ma.ws_floats * sizeof(float)) != hipSuccess) return PU_ERR_NOMEM;
+  int rc = PU_OK;
+  if (hipMemsetAsync(out_scalars, 0, PU_NUM_SCALARS * sizeof(float), s) != hipSuccess) rc = PU_ERR_HIP;
+  if (rc == PU_OK && launch_wmse_msssim(ma, s) != hipSuccess) rc = PU_ERR_HIP;
+  if (hipStreamSynchronize(s) != hipSuccess) rc = PU_ERR_HIP;
+  (void)hipFree(ma.ws);
+  return rc;
+}
+int pu_sample(pu_ctx* c, const float* x, const float* target, const float* eps, int B, int n, float* out, float* mu, float* sigma, void* stream) {
+  return sample_impl(c, x, target, eps, B, n, out, mu, sigma, nullptr, nullptr, 0.f, 0, 0.f, stream);
+}
+int pu_sample_hr(pu_ctx* c, const float* x, const float* target, const float* eps, int B, int n, const float* lrinterp, const float* resid_std,
+                 float epsilon, int softplus, float softplus_c, float* out, float* mu, float* sigma, void* stream) {
+  if (!lrinterp || !resid_std) return PU_ERR_INVALID;
+  return sample_impl(c, x, target, eps, B, n, out, mu, sigma, lrinterp, resid_std, epsilon, softplus, softplus_c, stream);
 }
 
 }  // extern "C"

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void fcomb_fwd_kernel(FcombArgs a, const float
         float acc = a.b2[co];
 #pragma unroll
         for (int c = 0; c < F; ++c) acc += a.w2[co * F + c] * h1[c];
-        a.out[(((long)b * a.M + m) * a.Cout + co) * HW + p] = acc;
+        a.out[(((long)b * a.M + m) * a.Cout + co) * HW + p] = fcomb_emit(a, b, co, p, HW, acc);
       }
     }
   }
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256) void fcomb_fwd16_kernel(FcombArgs f, const flo
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int co = fc_row(r, h);
-          if (co < f.Cout) f.out[(((long)b * f.M + m) * f.Cout + co) * HW + pix] = acc[r];
+          if (co < f.Cout) f.out[(((long)b * f.M + m) * f.Cout + co) * HW + pix] = fcomb_emit(f, b, co, pix, HW, acc[r]);
         }
       }
     }

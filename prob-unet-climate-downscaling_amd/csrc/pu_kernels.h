@@ -127,7 +127,18 @@ struct FcombArgs {
   const float* w0; const float* b0; const float* w1; const float* b1; const float* w2; const float* b2;  // fp32 params (reference layout)
   int F, L, Cout, B, M;
   float* out;                  // fp32 [B,M,Cout,H,W]
+  // optional fused reconstruction to physical units (ClimExDataset.residual_to_hr, climex_utils.py:277-285):
+  //   out = hr_base[b,co,p] + out * (hr_std[co,p] + hr_eps), then softplus (climex_utils.py:41-45) when hr_softplus != 0
+  const float* hr_base; const float* hr_std; float hr_eps; int hr_softplus; float hr_softplus_c;
 };
+// the value the Fcomb forward stores for residual `v` of sample b, plane co, pixel p
+__device__ __forceinline__ float fcomb_emit(const FcombArgs& a, int b, int co, long p, long HW, float v) {
+  if (a.hr_base) {
+    v = a.hr_base[((long)b * a.Cout + co) * HW + p] + v * (a.hr_std[(long)co * HW + p] + a.hr_eps);
+    if (a.hr_softplus) v = v > 20.f ? v : logf(expf(v) + 1.f) - a.hr_softplus_c;
+  }
+  return v;
+}
 template <typename T> hipError_t launch_fcomb_fwd(const FcombArgs&, hipStream_t);
 struct FcombBwdArgs {
   FcombArgs f;
@@ -151,5 +162,23 @@ void prof_enable(bool on);
 bool prof_enabled();
 void prof_record(const char* name, double flops, double bytes, hipStream_t s, bool begin);
 int prof_collect(ProfEntry* out, int max_entries);   // syncs the recorded events; clears the log
+
+// WMSE-MS-SSIM reconstruction loss (kernels_msssim.hip)
+struct MsssimArgs {
+  const float* pred;          // fp32 [B,M,C,H,W]
+  const float* target;        // fp32 [B,C,H,W]
+  int B, M, C, H, W;
+  float alpha_w, beta_w, lam_w;
+  float data_range;           // <= 0: inferred from the target on the device
+  float gscale;               // dpred = gscale * d(recon)/d(pred)
+  float* ws; size_t ws_floats;     // workspace of msssim_ws_floats() floats
+  float* scalars;             // PU_S_RECON is ADDED to, PU_S_WMSE added to (zero them first), PU_S_MSSSIM written
+  float* dpred;               // fp32 [B,M,C,H,W] written, or null (forward only)
+};
+size_t msssim_ws_floats(int B, int M, int C, int H, int W);
+hipError_t launch_wmse_msssim(const MsssimArgs&, hipStream_t);
+hipError_t launch_lrinterp_residuals(const float* hr, int B, int C, int H, int W, int k, const float* mean, const float* stdv, float eps,
+                                     float* inputs, float* targets, float* lrinterp, float* lr, hipStream_t s);
+hipError_t launch_lr_stats(const float* hr, int N, int C, int H, int W, int k, float* mean_lr, float* std_lr, float* mean_hr, float* std_hr, hipStream_t s);
 
 }  // namespace pu

@@ -243,7 +243,7 @@ class ProbabilisticUNet(nn.Module):
     """MI355X engine behind the reference constructor signature (prob_unet.py:146).
 
     Extra keyword-only arguments (all optional): dtype ("f32" parity path | "f16" | "bf16" MFMA paths),
-    max_batch / max_members (engine planning; grown on demand), recon ("afcrps" | "l1"), dropout.
+    max_batch / max_members (engine planning; grown on demand), recon ("afcrps" | "l1" | "wmse_msssim"), dropout.
     """
 
     def __init__(self, input_channels, num_classes, latent_dim, num_filters, model_channels, channel_mult,
@@ -262,6 +262,8 @@ class ProbabilisticUNet(nn.Module):
         if dtype not in L.DTYPES:
             raise ValueError(f"dtype must be one of {sorted(L.DTYPES)}")
         self.compute_dtype = dtype
+        if recon not in ("afcrps", "l1", "wmse_msssim"):
+            raise ValueError('recon must be "afcrps", "l1" or "wmse_msssim"')
         self.recon = recon
         self.dropout = float(dropout)
         self.sync_scalars = True          # reference returns python floats (.item()); set False to keep device scalars
@@ -569,12 +571,16 @@ class ProbabilisticUNet(nn.Module):
             z = self.prior_latent_space.rsample()
         return self.fcomb(unet_features, z)
 
-    def elbo(self, x, target, t=None, M: int = 5, alpha: float = 0.95, eps: Optional[torch.Tensor] = None):
+    def elbo(self, x, target, t=None, M: Optional[int] = None, alpha: float = 0.95, eps: Optional[torch.Tensor] = None,
+             alpha_w: float = 0.007, beta_w: float = 0.048, lam_w: float = 0.0, data_range: Optional[float] = None):
         """Fused ELBO forward(+backward when grad is enabled).
 
-        recon == "afcrps" (prob_unet.py:273-317; what train_prob_unet_model.py:133 unpacks):
+        recon == "afcrps" (prob_unet.py:273-317; what train_prob_unet_model.py:133 unpacks), M defaults to 5:
             returns (total_loss, [crps], kl_div[B])
         recon == "l1" (prob_unet.py:325-381): returns (total_loss, [l1], kl_div[B], kl_div2[B])
+        recon == "wmse_msssim" (the live elbo, prob_unet.py:229-267), M defaults to 1 as there; alpha_w / beta_w / lam_w are its
+            keyword arguments; returns (total_loss, [recon], kl_div[B], wmse, msssim) with the last member's wmse and
+            (1 - MS-SSIM).  data_range=None infers max(target) - min(target) on the device (prob_unet_utils.py:288-289).
         eps: optional explicit reparameterisation noise [M, B, L] (default: torch.randn on the device generator).
         """
         x = self._prep(x); target = self._prep(target)
@@ -587,9 +593,14 @@ class ProbabilisticUNet(nn.Module):
             else:
                 raise ValueError(f"expected {self.num_classes} target planes, got {target.shape[1]}")
         afcrps = self.recon == "afcrps"
+        msssim = self.recon == "wmse_msssim"
+        if M is None:
+            M = 5 if afcrps else 1
         if afcrps and M < 2:
             raise ValueError(f"M must be at least 2 to compute afCRPS but got M={M}")
-        Mx = M if afcrps else 1
+        if msssim and min(H, W) <= 96:
+            raise AssertionError("Image size should be larger than 96 due to the 4 downsamplings in ms-ssim")
+        Mx = M if (afcrps or msssim) else 1
         self._ensure(H, W, B, Mx)
         self._params_dirty()
         if eps is None:
@@ -600,10 +611,13 @@ class ProbabilisticUNet(nn.Module):
         with_bwd = 1 if torch.is_grad_enabled() else 0
         scal = torch.empty(L.PU_NUM_SCALARS, device=x.device, dtype=torch.float32)
         klv = torch.empty(B, device=x.device, dtype=torch.float32)
-        kl2v = None if afcrps else torch.empty(B, device=x.device, dtype=torch.float32)
+        kl2v = torch.empty(B, device=x.device, dtype=torch.float32) if self.recon == "l1" else None
         train = 1 if (self.training and self.dropout > 0) else 0
-        L.check(L.lib().pu_elbo_fwd_bwd(self._ctx, L.ptr(x), L.ptr(target), L.ptr(eps), B, Mx,
-                                        L.PU_RECON_AFCRPS if afcrps else L.PU_RECON_L1,
+        kind = L.PU_RECON_AFCRPS if afcrps else (L.PU_RECON_WMSE_MSSSIM if msssim else L.PU_RECON_L1)
+        if msssim:
+            L.check(L.lib().pu_set_recon_wmse_msssim(self._ctx, float(alpha_w), float(beta_w), float(lam_w),
+                                                     -1.0 if data_range is None else float(data_range)), self._ctx, "pu_set_recon_wmse_msssim")
+        L.check(L.lib().pu_elbo_fwd_bwd(self._ctx, L.ptr(x), L.ptr(target), L.ptr(eps), B, Mx, kind,
                                         float(self.beta_0), float(self.beta_1), float(self.beta_2), float(alpha), train,
                                         self._next_seed(), with_bwd, L.ptr(scal), L.ptr(klv), L.ptr(kl2v), L.current_stream()),
                 self._ctx, "pu_elbo_fwd_bwd")
@@ -611,10 +625,19 @@ class ProbabilisticUNet(nn.Module):
         if with_bwd:
             total = _DeliverGrads.apply(total, self._anchor_t(), self, 0, self._nparams)
         recon = scal[L.PU_S_RECON]
-        recon_list = [recon.item()] if self.sync_scalars else [recon]
         self._last_scalars = scal
+        if self.sync_scalars:
+            host = scal.tolist()                                  # one device->host sync for every logged scalar
+            recon_list = [host[L.PU_S_RECON]]
+        else:
+            host = None
+            recon_list = [recon]
         if afcrps:
             return total, recon_list, klv
+        if msssim:
+            if host is not None:
+                return total, recon_list, klv, host[L.PU_S_WMSE], host[L.PU_S_MSSSIM]
+            return total, recon_list, klv, scal[L.PU_S_WMSE], scal[L.PU_S_MSSSIM]
         return total, recon_list, klv, kl2v
 
     @torch.no_grad()
@@ -641,9 +664,43 @@ class ProbabilisticUNet(nn.Module):
             return out, Independent(Normal(loc=mu, scale=sg), 1)
         return out
 
+    @torch.no_grad()
+    def sample_hr(self, x, n: int, lrinterp, residual_std, epsilon: float = 1e-10, softplus: bool = False, softplus_c: float = 1e-7,
+                  target=None, eps: Optional[torch.Tensor] = None):
+        """`sample()` with ClimExDataset.residual_to_hr (climex_utils.py:277-285) fused into the Fcomb store: returns
+        physical-unit fields hr[b, s] = lrinterp[b] + residual[b, s] * (residual_std + epsilon), [B, n, Cout, H, W], without the
+        per-sample `.cpu()` round trip of train_prob_unet_model.py:246.  softplus=True additionally applies
+        climex_utils.softplus (:41-45), the inverse of the precipitation pre-transform."""
+        x = self._prep(x)
+        B, Cc, H, W = x.shape
+        self._ensure(H, W, B, n)
+        self._params_dirty()
+        if target is not None:
+            target = self._prep(target)
+            if target.shape[1] != self.num_classes:
+                target = target[:, : self.num_classes].contiguous()
+        lrinterp = self._prep(lrinterp)
+        if lrinterp.shape[1] != self.num_classes:
+            lrinterp = lrinterp[:, : self.num_classes].contiguous()
+        residual_std = residual_std.to(device=x.device, dtype=torch.float32)
+        if residual_std.dim() == 4:
+            residual_std = residual_std[0]
+        residual_std = residual_std[: self.num_classes].contiguous()
+        if tuple(lrinterp.shape) != (B, self.num_classes, H, W) or tuple(residual_std.shape) != (self.num_classes, H, W):
+            raise ValueError("lrinterp must be [B, Cout, H, W] and residual_std [Cout, H, W]")
+        if eps is None:
+            eps = torch.randn(n, B, self.latent_dim, device=x.device, dtype=torch.float32)
+        eps = eps.contiguous().float()
+        out = torch.empty(B, n, self.num_classes, H, W, device=x.device, dtype=torch.float32)
+        L.check(L.lib().pu_sample_hr(self._ctx, L.ptr(x), L.ptr(target), L.ptr(eps), B, n, L.ptr(lrinterp), L.ptr(residual_std),
+                                     float(epsilon), 1 if softplus else 0, float(softplus_c), L.ptr(out), None, None, L.current_stream()),
+                self._ctx, "pu_sample_hr")
+        return out
+
     @staticmethod
     def reconstruct(residual, lrinterp, residual_std, epsilon: float = 1e-10):
-        """climex_utils.py:277-285 (`lrinterp_to_residuals` datasets): hr = lrinterp + residual * (std + eps)."""
+        """climex_utils.py:277-285 (`lrinterp_to_residuals` datasets): hr = lrinterp + residual * (std + eps) on tensors that
+        already exist (torch arithmetic; `sample_hr` is the fused on-device path)."""
         return lrinterp + residual * (residual_std + epsilon)
 
     def elbo_fwd_flops(self, B, M):

@@ -3,6 +3,7 @@
  - libprobunet.so loads and exports every symbol include/probunet.h declares (no compute calls)
  - error behaviour without a device; load_state_dict of a reference-shaped (2*Cin plane) posterior stem."""
 import ctypes, os, re
+import numpy as np
 import pytest, torch
 import probunet_amd as pa
 from probunet_amd import _lib as L
@@ -103,3 +104,80 @@ def test_library_exports_every_declared_symbol():
     assert L.lib().pu_abi_version() == 1
     assert ctypes.sizeof(L.PuConfig) == 4 * (4 + 8 + 1 + 8 + 2 + 2 + 1) + 4 + 4
     assert ctypes.sizeof(L.PuParamDesc) == 96 + 4 + 16 + 4 + 8 + 8 or ctypes.sizeof(L.PuParamDesc) % 8 == 0
+
+
+# ------------------------------------------------------------------ rows f1-f4 (host logic + oracle pins, no GPU)
+def test_wmse_half_of_live_loss_matches_reference_golden():
+    """wmse_ms_ssim_loss (prob_unet_utils.py:270-305) with the absent third-party ms_ssim replaced by the same recording
+    constant tools/make_golden.py used: WMSE, lam-combination, inferred data_range, gradient, and the ensemble-mean rule."""
+    import json, os
+    from tests.filler import make_fields, checksum
+    from tests.helpers import GOLDEN
+    g = json.load(open(os.path.join(GOLDEN, "wmse.json")))
+    for tag, d in g.items():
+        x, y = make_fields(d["B"], d["C"], d["C"], d["H"], d["H"], seed=77)
+        pred = (0.8 * y + 0.3 * x).requires_grad_(True); tgt = 3.0 * y + 1.0
+        seen = {}
+        def fake(p, t_, data_range=None, win_size=None, size_average=True):
+            seen.update(dr=data_range, win=win_size); return torch.tensor(0.25)
+        loss, wmse, msl = O.wmse_ms_ssim_loss(pred, tgt, d["alpha"], d["beta"], d["lam"], ms_ssim_fn=fake)
+        loss.backward()
+        assert abs(float(loss) - d["loss"]) < 1e-6 * (1 + abs(d["loss"])) and abs(float(wmse) - d["wmse"]) < 1e-6 * (1 + d["wmse"])
+        assert abs(seen["dr"] - d["data_range"]) < 1e-6 and seen["win"] == d["win_size"] == 7
+        c = checksum(pred.grad)
+        assert abs(c["sum"] - d["grad"]["sum"]) < 1e-6 and abs(c["abssum"] - d["grad"]["abssum"]) < 1e-6
+        ens = torch.stack([pred.detach(), pred.detach() * 0.5], dim=1)
+        _, w5, _ = O.wmse_ms_ssim_loss(ens, tgt, d["alpha"], d["beta"], d["lam"], ms_ssim_fn=fake)
+        assert abs(float(w5) - d["wmse_ens_mean"]) < 1e-6 * (1 + d["wmse_ens_mean"])
+
+
+def test_ms_ssim_restatement_known_answers():
+    """PARITY UNPINNED arithmetic (pytorch-msssim 1.0.0 absent): properties of the published algorithm that do not need the
+    package - identity, symmetry, constant images (cs = 1, ms = l^0.1333), the size assertion, window normalisation."""
+    a = torch.rand(2, 1, 128, 112, generator=torch.Generator().manual_seed(1))
+    b = torch.rand(2, 1, 128, 112, generator=torch.Generator().manual_seed(2))
+    assert abs(float(O.ms_ssim(a, a, 1.0)) - 1.0) < 1e-6
+    assert abs(float(O.ms_ssim(a, b, 1.0)) - float(O.ms_ssim(b, a, 1.0))) < 1e-6
+    assert 0.0 <= float(O.ms_ssim(a, b, 1.0)) < 0.5
+    c1, c2, R = 0.8, 0.5, 2.0
+    v = float(O.ms_ssim(torch.full((1, 1, 128, 128), c1), torch.full((1, 1, 128, 128), c2), R))   # 128 -> 8: no padded (odd) level
+    C1 = (0.01 * R) ** 2
+    assert abs(v - ((2 * c1 * c2 + C1) / (c1 * c1 + c2 * c2 + C1)) ** 0.1333) < 1e-4      # fp32 E[x^2] - mu^2 noise against C2
+    with pytest.raises(AssertionError):
+        O.ms_ssim(a[..., :96, :96], b[..., :96, :96], 1.0)
+    w = O.gauss_window()
+    assert w.numel() == 7 and abs(float(w.sum()) - 1.0) < 1e-6 and float(w[3]) == float(w.max())
+
+
+def test_beta_schedule_matches_main_loop():
+    """main.py:108-155 replayed literally for num_epochs = 10: betas used for epochs 1..10."""
+    import probunet_amd as pa
+    used, b0, b1 = [], 1.0, 0.0
+    for epoch in range(1, 11):
+        used.append((b0, b1))
+        if epoch <= 2: b0, b1 = 1.0, 0.0
+        else: b0, b1 = 1.0, min((epoch - 2) / (10 - 2), 1.0) * 1.0
+    mine, cur = [], pa.trainer.beta_schedule(0, 10)
+    for epoch in range(1, 11):
+        mine.append(cur); cur = pa.trainer.beta_schedule(epoch, 10)
+    assert mine == used and pa.trainer.beta_schedule(10, 10) == (1.0, 1.0)
+
+
+def test_climex_oracle_transforms_round_trip():
+    hr = torch.randn(6, 2, 16, 24, generator=torch.Generator().manual_seed(3)) + 2.0
+    (ml, sl), (mh, sh) = O.lr_stats(hr, 4)
+    assert ml.shape == (2, 4, 6) and mh.shape == (2, 16, 24) and torch.equal(mh[:, ::4, ::4], ml)
+    it = O.lrinterp_to_residuals(hr, 4, mh, sh)
+    back = O.residual_to_hr(it["targets"], it["lrinterp"], sh)
+    assert float((back - hr).abs().max()) < 1e-4
+    assert torch.equal(O.softplus_climex(torch.tensor([25.0])), torch.tensor([25.0]))
+    assert abs(float(O.softplus_climex(torch.tensor([0.0]))) - (np.log(2.0) - 1e-7)) < 1e-6
+
+
+def test_data_module_has_no_cpu_fallback():
+    import probunet_amd as pa
+    from probunet_amd import _lib as L_
+    with pytest.raises(L_.ProbUNetLibraryError):
+        pa.data.lrinterp_to_residuals(torch.zeros(1, 1, 8, 8), 2, torch.zeros(1, 8, 8), torch.ones(1, 8, 8))
+    with pytest.raises(ValueError):
+        pa.ProbabilisticUNet(1, 1, 2, [8], 8, [1], 1.0, 1.0, 0.0, recon="ssim")

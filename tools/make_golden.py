@@ -159,6 +159,35 @@ def run_config(name, spec):
     print(name, "total", float(total), "crps", float(crps), "feat|max|", float(feat.abs().max()))
 
 
+def run_wmse():
+    """WMSE half + the loss combination + the data_range inference of wmse_ms_ssim_loss (prob_unet_utils.py:270-305), with the
+    absent third-party ms_ssim replaced by a recording constant (its own arithmetic stays unpinned)."""
+    seen = {}
+    def fake_ms_ssim(pred, target, data_range=None, size_average=True, win_size=None):
+        seen.update(data_range=float(data_range), win_size=win_size, size_average=size_average)
+        return torch.tensor(0.25)
+    ref_utils.ms_ssim = fake_ms_ssim
+    out = {}
+    for tag, (B, C, H, lam) in {"a": (2, 1, 24, 1.0), "b": (3, 2, 16, 0.3)}.items():
+        x, y = make_fields(B, C, C, H, H, seed=77)
+        pred = (0.8 * y + 0.3 * x).requires_grad_(True)
+        tgt = 3.0 * y + 1.0                                     # wide range so that min(alpha e^{beta y}, 1) is exercised
+        loss, wmse, msl = ref_utils.wmse_ms_ssim_loss(pred, tgt, alpha=0.5, beta=0.4, lam=lam, return_components=True)
+        loss.backward()
+        out[tag] = dict(B=B, C=C, H=H, lam=lam, alpha=0.5, beta=0.4, loss=float(loss), wmse=float(wmse), msssim_loss=float(msl),
+                        data_range=seen["data_range"], win_size=seen["win_size"], grad=checksum(pred.grad))
+        ens = torch.stack([pred.detach(), pred.detach() * 0.5], dim=1)          # 5-D input: the ensemble mean is used (:283-284)
+        l5, w5, _ = ref_utils.wmse_ms_ssim_loss(ens, tgt, alpha=0.5, beta=0.4, lam=lam, return_components=True)
+        out[tag]["wmse_ens_mean"] = float(w5)
+    with open(os.path.join(OUT, "wmse.json"), "w") as f:
+        json.dump(out, f)
+    print("wmse", out["a"]["wmse"], out["b"]["loss"])
+
+
 if __name__ == "__main__":
-    for n, s in CONFIGS.items():
-        run_config(n, s)
+    if len(sys.argv) > 1 and sys.argv[1] == "wmse":
+        run_wmse()
+    else:
+        for n, s in CONFIGS.items():
+            run_config(n, s)
+        run_wmse()
