@@ -52,11 +52,11 @@ def perturb_zero_init(model, seed=7):
                 p.copy_((torch.randn(p.shape, generator=g) * (0.5 / fan_in ** 0.5)).to(p.device))
 
 
-def build_model(cfg, dtype, device):
+def build_model(cfg, dtype, device, recon="afcrps"):
     import probunet_amd as pa
     torch.manual_seed(42)
     m = pa.ProbabilisticUNet(cfg["input_channels"], cfg["num_classes"], cfg["latent_dim"], cfg["num_filters"], cfg["model_channels"],
-                             cfg["channel_mult"], 1.0, 1.0, 0.0, dtype=dtype, max_batch=cfg["batch"], max_members=cfg["M"])
+                             cfg["channel_mult"], 1.0, 1.0, 0.0, dtype=dtype, max_batch=cfg["batch"], max_members=cfg["M"], recon=recon)
     perturb_zero_init(m)
     return m.to(device).train()
 
@@ -124,12 +124,17 @@ def bench_sample(args):
     cfg = dict(CFG3, batch=B, M=args.samples)
     model = build_model(cfg, args.dtype, device).eval()
     x, _ = synthetic_fields(B, cfg["input_channels"], cfg["num_classes"], cfg["H"], cfg["W"], 4321, device)
+    if args.hr:       # physical-unit fields: residual_to_hr fused into the Fcomb store (row f3)
+        lrinterp = x[:, : cfg["num_classes"]].contiguous(); std = torch.rand(cfg["num_classes"], cfg["H"], cfg["W"], device=device) + 0.5
+        draw = lambda: model.sample_hr(x, args.samples, lrinterp, std)
+    else:
+        draw = lambda: model.sample(x, args.samples)
     for _ in range(args.warmup):
-        model.sample(x, args.samples)
+        draw()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = model.sample(x, args.samples)
+        out = draw()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
     # Fcomb-only rate (features and prior fixed, the inner loop of latent_exploration.py:119-129)
@@ -146,7 +151,7 @@ def bench_sample(args):
                           unit="samples/s", n_gpus=1, steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * el / args.steps, 3),
                           higher_is_better=True, scaling="weak", vs_baseline=None, dtype=args.dtype, data="synthetic",
                           config=dict(workload=f"cfg5: 4->1, 256x256, latent 12, depth-5 U-Net, {B} inputs x {args.samples} prior samples per call "
-                                               "(U-Net + prior once, then the fused Fcomb per sample)",
+                                               "(U-Net + prior once, then the fused Fcomb per sample)" + (" + fused residual_to_hr" if args.hr else ""),
                                       fcomb_only_samples_per_s=round(args.samples * 20 / el2, 1)))), flush=True)
 
 
@@ -164,6 +169,9 @@ def main():
     ap.add_argument("--mode", default="train", choices=["train", "sample"],
                     help="sample = BASELINE config 5: prior samples/s, 64 samples per lo-res input (U-Net + prior once, 64 x Fcomb)")
     ap.add_argument("--samples", type=int, default=64)
+    ap.add_argument("--hr", action="store_true", help="sample mode: emit physical-unit fields (fused residual_to_hr)")
+    ap.add_argument("--recon", default="afcrps", choices=["afcrps", "wmse_msssim", "l1"],
+                    help="reconstruction term; afcrps is the reported metric, wmse_msssim is the reference's live elbo (diagnostic)")
     args = ap.parse_args()
     if args.mode == "sample":
         return bench_sample(args)
@@ -183,7 +191,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     cfg = dict(CFG3, batch=args.batch, M=args.members)
-    model = build_model(cfg, args.dtype, device)
+    model = build_model(cfg, args.dtype, device, args.recon)
     model.sync_scalars = False                       # keep the loss scalars on the device: no .item() sync per step
     torch.manual_seed(1234 + rank)                   # rank-offset reparameterisation noise (dropout seeds are rank-offset inside the model)
     if world > 1:
@@ -200,7 +208,7 @@ def main():
     t_stamp = torch.zeros(cfg["batch"], 1, device=device)
 
     def step():
-        loss, recon_list, kl_div = model.elbo(x, y, t_stamp, M=cfg["M"])        # train_prob_unet_model.py:133
+        loss, recon_list, kl_div = model.elbo(x, y, t_stamp, M=cfg["M"])[:3]    # train_prob_unet_model.py:133
         opt.zero_grad()
         loss.backward()
         if not args.no_optimizer:
@@ -263,7 +271,7 @@ def main():
                n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_per_step, 3), higher_is_better=True,
                scaling="weak", vs_baseline=None, dtype=args.dtype, data="synthetic",
                config=dict(workload=f"cfg3: 4->1 planes, 256x256, latent 12, depth-5 U-Net, {cfg['batch']} field pairs per GPU, "
-                                    f"afCRPS-ELBO M={cfg['M']} fwd+bwd, train mode (dropout 0.1)"
+                                    f"{'afCRPS' if args.recon == 'afcrps' else args.recon}-ELBO M={cfg['M']} fwd+bwd, train mode (dropout 0.1)"
                                     + ("" if args.no_optimizer else (" + fused flat AdamW step" if args.flat_adamw else " + AdamW step")) + (" + RCCL grad all-reduce" if world > 1 else ""),
                            global_batch=world * cfg["batch"], parallelism=f"dp{world}",
                            elbo_fwd_bwd_tflop_per_step=round(3 * fwd_flops / 1e12, 3),

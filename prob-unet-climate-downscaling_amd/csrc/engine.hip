@@ -611,8 +611,8 @@ static int unet_forward(pu_ctx* c, int B, int train, uint64_t seed, hipStream_t 
   return PU_OK;
 }
 // expects feat.g filled; clears/uses the gradient flags of all U-Net tensors
-template <typename T>
-static int unet_backward(pu_ctx* c, hipStream_t s) {
+template <typename T, typename Mid>
+static int unet_backward(pu_ctx* c, hipStream_t s, Mid&& mid) {
   int r; const int B = c->unet_B, train = c->unet_train; const uint64_t seed = c->unet_seed;
   if (B <= 0) FAIL(PU_ERR_STATE, "U-Net backward without a forward");
   std::fill(c->flags.begin(), c->flags.end(), 0);
@@ -620,7 +620,11 @@ static int unet_backward(pu_ctx* c, hipStream_t s) {
   if ((r = conv_wgrad<T>(c, c->out_conv, c->feat.g, c->out_a.v, B, s, G(c, c->out_conv.b_off), nullptr))) return r;
   if ((r = conv_dgrad<T>(c, c->out_conv, c->feat.g, c->out_a.g, B, 0, s))) return r;
   if ((r = gn_bwd<T>(c, c->out_norm, last.v, c->out_a.v, c->out_a.g, last.g, take_acc(c, last), B, train, seed, s))) return r;
-  for (int j = (int)c->dec.size() - 1; j >= 0; --j) if ((r = block_bwd<T>(c, c->dec[j], B, train, seed, true, s))) return r;
+  const int jmid = (int)c->dec.size() * 2 / 3;           // `mid` is enqueued after the first third of the decoder blocks
+  for (int j = (int)c->dec.size() - 1; j >= 0; --j) {
+    if ((r = block_bwd<T>(c, c->dec[j], B, train, seed, true, s))) return r;
+    if (j == jmid && (r = mid())) return r;
+  }
   for (int i = (int)c->enc.size() - 1; i >= 0; --i) if ((r = block_bwd<T>(c, c->enc[i], B, train, seed, i > 0, s))) return r;
   return PU_OK;
 }
@@ -809,7 +813,7 @@ int pu_unet_bwd(pu_ctx* c, const float* dfeat, void* stream) {
     c->inv_scale = 1.f;
     const int F = c->cfg.num_filters[0]; const long HW = (long)c->cfg.H * c->cfg.W;
     CKH(launch_nchw_to_nhwc<T>(dfeat, (long)F * HW, F, nullptr, 0, with_b(c->feat.g, B), s));
-    int q = unet_backward<T>(c, s); if (q) return q;
+    int q = unet_backward<T>(c, s, []() -> int { return PU_OK; }); if (q) return q;
     return join_side(c, s);
   });
 }
@@ -968,10 +972,15 @@ int pu_elbo_fwd_bwd(pu_ctx* c, const float* x, const float* target, const float*
     lb.f = la; lb.dz = c->dz; lb.beta1 = beta1 * S; lb.beta2 = l1 ? beta2 * S : 0.f;
     lb.dmu_q = c->post.dmu; lb.dls_q = c->post.dls; lb.dmu_p = c->prior.dmu; lb.dls_p = c->prior.dls;
     CKH(launch_latent_bwd(lb, s));
+    // host enqueue order: the latent encoders' backward goes to the second side stream once the first U-Net decoder blocks
+    // are queued (the host runs only ~1 ms ahead of the GPU here: enqueued last, they would start when the U-Net chain ends
+    // and leave a ~4 ms tail; enqueued first, their ~100 launches would delay the critical chain)
     if ((q = fork2(c, s, &s2))) return q;
-    if ((q = unet_backward<T>(c, s))) return q;
-    if ((q = gauss_backward<T>(c, c->post, s2))) return q;
-    if ((q = gauss_backward<T>(c, c->prior, s2))) return q;
+    if ((q = unet_backward<T>(c, s, [&]() -> int {
+          int e;
+          if ((e = gauss_backward<T>(c, c->post, s2))) return e;
+          return gauss_backward<T>(c, c->prior, s2);
+        }))) return q;
     if ((q = join2(c, s, s2))) return q;
     return join_side(c, s);
   });

@@ -31,18 +31,33 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
   return red[0] + red[1] + red[2] + red[3];
 }
 
-// value range of the target: R = max(max - min, 1e-5)   (prob_unet_utils.py:288-289); one block
-__global__ __launch_bounds__(1024) void ms_range_kernel(const float* __restrict__ y, long n, float fixed, float* __restrict__ dr) {
-  __shared__ float smn[16], smx[16];
-  if (fixed > 0.f) { if (threadIdx.x == 0) dr[0] = fixed; return; }
+// value range of the target: R = max(max - min, 1e-5)   (prob_unet_utils.py:288-289).  Two stages: per-block (min, max)
+// partials, then one block folds them (deterministic, no float atomics).
+constexpr int RANGE_BLOCKS = 256;
+__global__ __launch_bounds__(256) void ms_range_partial_kernel(const float* __restrict__ y, long n, float* __restrict__ part) {
+  __shared__ float smn[4], smx[4];
   float mn = INFINITY, mx = -INFINITY;
-  for (long i = threadIdx.x; i < n; i += 1024) { const float v = y[i]; mn = fminf(mn, v); mx = fmaxf(mx, v); }
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) { const float v = y[i]; mn = fminf(mn, v); mx = fmaxf(mx, v); }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) { mn = fminf(mn, __shfl_xor(mn, off)); mx = fmaxf(mx, __shfl_xor(mx, off)); }
   if ((threadIdx.x & 63) == 0) { smn[threadIdx.x >> 6] = mn; smx[threadIdx.x >> 6] = mx; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    for (int i = 1; i < 16; ++i) { mn = fminf(mn, smn[i]); mx = fmaxf(mx, smx[i]); }
+    part[blockIdx.x * 2] = fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3]));
+    part[blockIdx.x * 2 + 1] = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+  }
+}
+__global__ __launch_bounds__(256) void ms_range_final_kernel(const float* __restrict__ part, int nblk, float fixed, float* __restrict__ dr) {
+  __shared__ float smn[4], smx[4];
+  if (fixed > 0.f) { if (threadIdx.x == 0) dr[0] = fixed; return; }
+  float mn = INFINITY, mx = -INFINITY;
+  for (int i = threadIdx.x; i < nblk; i += 256) { mn = fminf(mn, part[i * 2]); mx = fmaxf(mx, part[i * 2 + 1]); }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { mn = fminf(mn, __shfl_xor(mn, off)); mx = fmaxf(mx, __shfl_xor(mx, off)); }
+  if ((threadIdx.x & 63) == 0) { smn[threadIdx.x >> 6] = mn; smx[threadIdx.x >> 6] = mx; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    mn = fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3])); mx = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
     dr[0] = fmaxf(mx - mn, 1e-5f);
   }
 }
@@ -293,7 +308,7 @@ constexpr size_t BWD_LDS = (size_t)(2 * TB * (TB + 1) + 5 * TB * TI + 3 * TI * (
 }  // namespace
 
 size_t msssim_ws_floats(int B, int M, int C, int H, int W) {
-  size_t n = 16;                                  // dr
+  size_t n = 16 + 2 * RANGE_BLOCKS;               // dr + range partials
   int h = H, w = W;
   const size_t NC = (size_t)B * M * C, BC = (size_t)B * C;
   for (int l = 0; l < NLV; ++l) {
@@ -314,7 +329,7 @@ hipError_t launch_wmse_msssim(const MsssimArgs& a, hipStream_t s) {
   const int NC = a.B * a.M * a.C, BC = a.B * a.C;
   // carve the workspace
   float* p = a.ws;
-  float* dr = p; p += 16;
+  float* dr = p; p += 16; float* rpart = p; p += 2 * RANGE_BLOCKS;
   LevelDims d; const float* Xl[NLV]; const float* Yl[NLV]; float* dXl[NLV]; float* partl[NLV];
   float* part0 = p; long poff = 0;
   int h = a.H, w = a.W;
@@ -331,7 +346,8 @@ hipError_t launch_wmse_msssim(const MsssimArgs& a, hipStream_t s) {
   }
   float* gco = p; p += (size_t)NC * NLV;
 
-  hipLaunchKernelGGL(ms_range_kernel, dim3(1), dim3(1024), 0, s, a.target, (long)BC * a.H * a.W, a.data_range, dr);
+  if (a.data_range <= 0.f) hipLaunchKernelGGL(ms_range_partial_kernel, dim3(RANGE_BLOCKS), dim3(256), 0, s, a.target, (long)BC * a.H * a.W, rpart);
+  hipLaunchKernelGGL(ms_range_final_kernel, dim3(1), dim3(256), 0, s, rpart, RANGE_BLOCKS, a.data_range, dr);
   {
     const long total = (long)NC * a.H * a.W;
     const unsigned g = (unsigned)(total / 256 / 8 > 2048 ? 2048 : (total / 256 / 8 < 1 ? 1 : total / 256 / 8));
