@@ -147,7 +147,14 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(TV x, const float* __r
         double a = 0, q = 0;
         if (c < Cs && lane < nl) {
           const float2* pp = reinterpret_cast<const float2*>(ps) + ((long)b * ns + lane) * Cs + c;
-          for (int k = lane; k < ns; k += nl, pp += (long)nl * Cs) { const float2 v = *pp; a += v.x; q += v.y; }
+          const long st = (long)nl * Cs;
+          int k = lane;
+          for (; k + 3 * nl < ns; k += 4 * nl, pp += 4 * st) {           // four independent loads in flight per trip
+            const float2 v0 = pp[0], v1 = pp[st], v2 = pp[2 * st], v3 = pp[3 * st];
+            a += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
+            q += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
+          }
+          for (; k < ns; k += nl, pp += st) { const float2 v = *pp; a += v.x; q += v.y; }
         }
         red[tid * 2] = a; red[tid * 2 + 1] = q;
         __syncthreads();
@@ -213,6 +220,39 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNArgs a) {
   const float4* cf = reinterpret_cast<const float4*>(a.coef) + ((long)b * C + cv * VEC);
 #pragma unroll
   for (int e = 0; e < VEC; ++e) { const float4 q4 = cf[e]; A[e] = q4.x; Bc[e] = q4.y; mu[e] = q4.z; }
+  if (RS == RS_NONE) {
+    // four pixels per trip, loads first (see gn_bwd_pass1_kernel)
+    constexpr int U = 4;
+    for (long p = p0 + pl; p < p1; p += (long)PL * U) {
+      V16 rx[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long pp = p + (long)u * PL;
+        rx[u] = ldv<T>(xp + ((long)b * OHW + (pp < p1 ? pp : p)) * a.x.ld + cv * VEC);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long pp = p + (long)u * PL;
+        if (pp < p1) {
+          float v[VEC], o[VEC];
+          unpack<T>(rx[u], v);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) o[e] = silu_f<sizeof(T) == 4>(A[e] * (v[e] - mu[e]) + Bc[e]);
+          if (a.drop_p > 0.f) {
+            const uint64_t base = ((uint64_t)(b + a.b0) * OHW + pp) * (uint64_t)C + (uint64_t)cv * VEC;
+#pragma unroll
+            for (int e = 0; e < VEC; e += 2) {
+              const uint32_t r = drop_pair(dkey, base + e);
+              o[e] = (r & 0xffffu) < dthr ? o[e] * inv_keep : 0.f;
+              o[e + 1] = (r >> 16) < dthr ? o[e + 1] * inv_keep : 0.f;
+            }
+          }
+          stv<T>(yp + ((long)b * OHW + pp) * a.y.ld + cv * VEC, pack<T>(o));
+        }
+      }
+    }
+    return;
+  }
   for (long p = p0 + pl; p < p1; p += PL) {
     const int oy = (int)(p / OW), ox = (int)(p - (long)oy * OW);
     float o[VEC];
@@ -368,13 +408,54 @@ __global__ __launch_bounds__(256) void gn_bwd_pass1_kernel(GNBwdArgs a) {
       A[e] = q4.x; Bc[e] = q4.y; mean[e] = q4.z; rstd[e] = q4.w;
       s1[e] = 0.f; s2[e] = 0.f;
     }
-    for (long p = p0 + pl; p < p1; p += PL) {
-      const int y = (int)(p / W), x = (int)(p % W);
-      float xv[VEC], dv[VEC];
-      unpack<T>(ldv<T>(xp + ((long)b * HW + p) * f.x.ld + cv * VEC), xv);
-      gn_dv<T, RS>(f, a.dy, b, y, x, p, cv, A, Bc, mean, xv, keep, inv_keep, dv);
+    if (RS == RS_NONE) {
+      // four pixels per trip with all eight 16-byte loads issued before the first use: a thread walks ~16 pixels, and one
+      // load -> exp -> accumulate round per pixel left this pass latency-bound (2.8 TB/s) rather than HBM-bound
+      constexpr int U = 4;
+      const T* dyp = reinterpret_cast<const T*>(a.dy.p);
+      const uint32_t dkey = drop_key(f.drop_seed, f.drop_stream), dthr = drop_thr16(keep);
+      for (long p = p0 + pl; p < p1; p += (long)PL * U) {
+        V16 rx[U], rd[U];
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) { s1[e] += dv[e]; s2[e] += dv[e] * (xv[e] - mean[e]) * rstd[e]; }
+        for (int u = 0; u < U; ++u) {
+          const long pp = p + (long)u * PL;
+          const long q = pp < p1 ? pp : p;                          // clamp: the duplicate is discarded below
+          rx[u] = ldv<T>(xp + ((long)b * HW + q) * f.x.ld + cv * VEC);
+          rd[u] = ldv<T>(dyp + ((long)b * HW + q) * a.dy.ld + cv * VEC);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const long pp = p + (long)u * PL;
+          if (pp < p1) {
+            float xv[VEC], dh[VEC];
+            unpack<T>(rx[u], xv); unpack<T>(rd[u], dh);
+            if (f.drop_p > 0.f) {
+              const uint64_t base = ((uint64_t)(b + f.b0) * HW + pp) * (uint64_t)C + (uint64_t)(cv * VEC);
+#pragma unroll
+              for (int e = 0; e < VEC; e += 2) {
+                const uint32_t r = drop_pair(dkey, base + e);
+                dh[e] = (r & 0xffffu) < dthr ? dh[e] * inv_keep : 0.f;
+                dh[e + 1] = (r >> 16) < dthr ? dh[e + 1] * inv_keep : 0.f;
+              }
+            }
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+              const float d = xv[e] - mean[e];
+              const float dv = dh[e] * dsilu_f<sizeof(T) == 4>(A[e] * d + Bc[e]);
+              s1[e] += dv; s2[e] += dv * d * rstd[e];
+            }
+          }
+        }
+      }
+    } else {
+      for (long p = p0 + pl; p < p1; p += PL) {
+        const int y = (int)(p / W), x = (int)(p % W);
+        float xv[VEC], dv[VEC];
+        unpack<T>(ldv<T>(xp + ((long)b * HW + p) * f.x.ld + cv * VEC), xv);
+        gn_dv<T, RS>(f, a.dy, b, y, x, p, cv, A, Bc, mean, xv, keep, inv_keep, dv);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { s1[e] += dv[e]; s2[e] += dv[e] * (xv[e] - mean[e]) * rstd[e]; }
+      }
     }
 #pragma unroll
     for (int e = 0; e < VEC; ++e) { buf[(pl * C + cv * VEC + e) * 2] = s1[e]; buf[(pl * C + cv * VEC + e) * 2 + 1] = s2[e]; }
@@ -394,12 +475,29 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(GNBwdArgs a) {
   const GNArgs& f = a.f;
   const int b = blockIdx.x, tid = threadIdx.x, C = f.x.C, G = f.G, cpg = C / G;
   const long HW = (long)f.x.H * f.x.W;
-  for (int c = tid; c < C; c += 256) {
-    float u = 0.f, w = 0.f;
-    for (int k = 0; k < f.nchunk; ++k) { const float* pp = a.part2 + (((long)b * f.nchunk + k) * C + c) * 2; u += pp[0]; w += pp[1]; }
-    cs[c * 2] = u; cs[c * 2 + 1] = w;
+  {
+    // per-channel totals of the pass-1 rows: nl threads share a channel (with C = 32 a one-thread-per-channel loop would
+    // leave 224 of the block's 256 threads idle behind 64 dependent loads)
+    __shared__ float red[256 * 2];
+    const float2* part = reinterpret_cast<const float2*>(a.part2);
+    const int nk = f.nchunk;
+    const int nl = C >= 256 ? 1 : 256 / C;
+    for (int c0 = 0; c0 < C; c0 += 256) {
+      const int c = nl > 1 ? tid % C : c0 + tid, lane = nl > 1 ? tid / C : 0;
+      float u = 0.f, w = 0.f;
+      if (c < C && lane < nl) {
+        const float2* pp = part + ((long)b * nk + lane) * C + c;
+        for (int k = lane; k < nk; k += nl, pp += (long)nl * C) { const float2 v = *pp; u += v.x; w += v.y; }
+      }
+      red[tid * 2] = u; red[tid * 2 + 1] = w;
+      __syncthreads();
+      if (c < C && lane == 0) {
+        for (int j = 1; j < nl; ++j) { u += red[(j * C + c) * 2]; w += red[(j * C + c) * 2 + 1]; }
+        cs[c * 2] = u; cs[c * 2 + 1] = w;
+      }
+      __syncthreads();
+    }
   }
-  __syncthreads();
   if (tid < G) {
     float m1 = 0.f, m2 = 0.f;
     for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) {
