@@ -546,6 +546,53 @@ __global__ __launch_bounds__(256) void gn_bwd_pass2_kernel(GNBwdArgs a) {
   const float* q2 = a.coef2 + ((long)b * C + cv * VEC) * 3;
 #pragma unroll
   for (int e = 0; e < VEC; ++e) { const float4 q4 = q1[e]; A[e] = q4.x; Bc[e] = q4.y; mu[e] = q4.z; c0[e] = q2[3 * e]; c1[e] = q2[3 * e + 1]; c2[e] = q2[3 * e + 2]; }
+  if (RS == RS_NONE) {
+    // four pixels per trip, every load issued before the first use (see gn_bwd_pass1_kernel)
+    constexpr int U = 4;
+    const T* dyp = reinterpret_cast<const T*>(a.dy.p);
+    const uint32_t dkey = drop_key(f.drop_seed, f.drop_stream), dthr = drop_thr16(keep);
+    for (long p = p0 + pl; p < p1; p += (long)PL * U) {
+      V16 rx[U], rd[U], ro[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long pp = p + (long)u * PL;
+        const long bp = (long)b * HW + (pp < p1 ? pp : p);
+        rx[u] = ldv<T>(xp + bp * f.x.ld + cv * VEC);
+        rd[u] = ldv<T>(dyp + bp * a.dy.ld + cv * VEC);
+        if (a.accumulate) ro[u] = ldv<T>(dxp + bp * a.dx.ld + cv * VEC);
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const long pp = p + (long)u * PL;
+        if (pp < p1) {
+          float xv[VEC], dh[VEC], o[VEC];
+          unpack<T>(rx[u], xv); unpack<T>(rd[u], dh);
+          if (f.drop_p > 0.f) {
+            const uint64_t base = ((uint64_t)(b + f.b0) * HW + pp) * (uint64_t)C + (uint64_t)(cv * VEC);
+#pragma unroll
+            for (int e = 0; e < VEC; e += 2) {
+              const uint32_t r = drop_pair(dkey, base + e);
+              dh[e] = (r & 0xffffu) < dthr ? dh[e] * inv_keep : 0.f;
+              dh[e + 1] = (r >> 16) < dthr ? dh[e + 1] * inv_keep : 0.f;
+            }
+          }
+          if (a.accumulate) unpack<T>(ro[u], o);
+          else {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) o[e] = 0.f;
+          }
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            const float d = xv[e] - mu[e];
+            const float dv = dh[e] * dsilu_f<sizeof(T) == 4>(A[e] * d + Bc[e]);
+            o[e] += c0[e] * dv + c1[e] * d + c2[e];
+          }
+          stv<T>(dxp + ((long)b * HW + pp) * a.dx.ld + cv * VEC, pack<T>(o));
+        }
+      }
+    }
+    return;
+  }
   for (long p = p0 + pl; p < p1; p += PL) {
     const long bp = (long)b * HW + p;
     float xv[VEC], dv[VEC], o[VEC];

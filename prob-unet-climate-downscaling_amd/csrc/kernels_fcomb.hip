@@ -366,6 +366,7 @@ __global__ __launch_bounds__(256) void fcomb_bwd16_kernel(FcombBwdArgs a, const 
   typedef FCM<T> M;
   extern __shared__ __attribute__((aligned(16))) unsigned char fc16_smem[];
   uint16_t* tiles = reinterpret_cast<uint16_t*>(fc16_smem);        // 6 x [128][32]: dout | h1 | dh1 | h0 | dh0 | feat
+  float* zbs = reinterpret_cast<float*>(fc16_smem + 6 * 128 * 32 * 2);   // [M][32]: this sample's per-member latent bias (L2 latency paid once)
   constexpr int CHP = 128, TS = CHP * 32;                          // pixels per chunk (4 waves x 32), tile stride
   const FcombArgs& f = a.f;
   const long HW = (long)f.feat.H * f.feat.W;
@@ -397,10 +398,21 @@ __global__ __launch_bounds__(256) void fcomb_bwd16_kernel(FcombBwdArgs a, const 
   // transposed-read lane roles
   const int g = l >> 4, q = (l & 15) >> 2, p = l & 3;
   const int nchunks = (int)((HW + CHP - 1) / CHP);
+  for (int i = tid; i < f.M * 32; i += 256) zbs[i] = zb[((long)(i >> 5) * f.B + b) * 32 + (i & 31)];
+  __syncthreads();
+  // dout of the next member is fetched while the current one is processed (HBM latency off the dependent chain).  Compact
+  // form for Cout <= 4 (rows 0..3 live in the h == 0 half of both layouts); wider outputs load in place.
+  const bool small_co = f.Cout <= 4;
+  auto load_dout4 = [&](int m, long pix, bool valid, float* dn) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dn[e] = (valid && small_co && h == 0 && e < f.Cout) ? a.dout[(((long)b * f.M + m) * f.Cout + e) * HW + pix] : 0.f;
+  };
   for (int ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
     // ---- per-wave: two 32-pixel column tiles; feat fragments and the shared pre-activation
     f32x16 pre, dfe;
-    __syncthreads();                                       // previous chunk's transposed reads are done
+    // every wave reads back (transposed) only the 32 pixel rows it wrote itself, and a wave's LDS operations execute in
+    // order: no block barrier anywhere in this loop, the four waves of a block run independently
+    __builtin_amdgcn_wave_barrier();
     const int lp = wave * 32 + j;                          // pixel inside the chunk
     const long pix = (long)ch * CHP + lp;
     const bool valid = pix < HW;
@@ -419,9 +431,13 @@ __global__ __launch_bounds__(256) void fcomb_bwd16_kernel(FcombBwdArgs a, const 
       pre = M::mfma(w.w0n[0], fb[0], pre);
       pre = M::mfma(w.w0n[1], fb[1], pre);
     }
+    float dn[4];
+    load_dout4(0, pix, valid, dn);
     for (int m = 0; m < f.M; ++m) {
-      const float* zbm = zb + ((long)m * f.B + b) * 32;
-      if (m > 0) __syncthreads();                          // previous member's transposed reads are done
+      const float* zbm = zbs + m * 32;
+      const float dc[4] = {dn[0], dn[1], dn[2], dn[3]};
+      if (m + 1 < f.M) load_dout4(m + 1, pix, valid, dn);
+      __builtin_amdgcn_wave_barrier();
       {
         f32x16 h0, h1, acc, d1, d0;
 #pragma unroll
@@ -437,7 +453,10 @@ __global__ __launch_bounds__(256) void fcomb_bwd16_kernel(FcombBwdArgs a, const 
         f32x16 dtile;
 #pragma unroll
         for (int r = 0; r < 16; ++r) dtile[r] = 0.f;
-        if (valid) {
+        if (small_co) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { M::set(fdo, e, dc[e]); dtile[e] = dc[e]; }      // rows 0..3 (zero on the h == 1 half)
+        } else if (valid) {
 #pragma unroll
           for (int e = 0; e < 8; ++e)
             if (8 * h + e < f.Cout) M::set(fdo, e, a.dout[(((long)b * f.M + m) * f.Cout + 8 * h + e) * HW + pix]);
@@ -473,13 +492,14 @@ __global__ __launch_bounds__(256) void fcomb_bwd16_kernel(FcombBwdArgs a, const 
         fc_store_tile<T>(tiles + 3 * TS, lp, h, h0);
         fc_store_tile<T>(tiles + 4 * TS, lp, h, d0);
       }
-      __syncthreads();
-      // ---- weight-gradient products over the chunk's 256 pixels: wave owns k-steps wave, wave+4, ...
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      // ---- weight-gradient products over the wave's own 32 pixels (two 16-pixel k-steps)
 #pragma unroll
       for (int r = 0; r < 16; ++r) az[r] = 0.f;
 #pragma unroll
-      for (int ks = 0; ks < CHP / 64; ++ks) {
-        const int kk = wave + 4 * ks;
+      for (int ks = 0; ks < 2; ++ks) {
+        const int kk = 2 * wave + ks;
         const int r0 = kk * 16 + 8 * h + q, r1 = r0 + 4;                      // pixel rows supplied by this lane
         const int c0 = ((2 * (g & 1) + (p >> 1)) ^ ((r0 >> 2) & 3)) * 8 + 4 * (p & 1);
         const int c1 = ((2 * (g & 1) + (p >> 1)) ^ ((r1 >> 2) & 3)) * 8 + 4 * (p & 1);
@@ -613,12 +633,12 @@ hipError_t launch_fcomb_bwd(const FcombBwdArgs& a, hipStream_t s) {
     if constexpr (sizeof(T) == 2) {
       static bool attr16 = false;
       if (!attr16) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(fcomb_bwd16_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 128 * 32 * 2);
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(fcomb_bwd16_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 128 * 32 * 2 + 256 * 32 * 4);
         if (e != hipSuccess) return e;
         attr16 = true;
       }
       dim3 grid16((unsigned)min((long)24, (HW + 127) / 128), f.B);
-      hipLaunchKernelGGL((fcomb_bwd16_kernel<T>), grid16, dim3(256), 6 * 128 * 32 * 2, s, a, zb, dzb);
+      hipLaunchKernelGGL((fcomb_bwd16_kernel<T>), grid16, dim3(256), 6 * 128 * 32 * 2 + (size_t)f.M * 32 * 4, s, a, zb, dzb);
     }
   } else if (f.F == 32) hipLaunchKernelGGL((fcomb_bwd_kernel<T, 32>), grid, dim3(256), lds, s, a, zb, dzb);
   else if (f.F == 16) hipLaunchKernelGGL((fcomb_bwd_kernel<T, 16>), grid, dim3(256), lds, s, a, zb, dzb);
