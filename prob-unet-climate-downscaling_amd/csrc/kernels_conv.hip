@@ -94,7 +94,7 @@ template <typename T> __device__ __forceinline__ void store4(T* p, const float* 
 template <> __device__ __forceinline__ void store4<float>(float* p, const float* o) { f32x4 v = {o[0], o[1], o[2], o[3]}; *reinterpret_cast<f32x4*>(p) = v; }
 template <> __device__ __forceinline__ void store4<f16>(f16* p, const float* o) { f16x4 v = {(f16)o[0], (f16)o[1], (f16)o[2], (f16)o[3]}; *reinterpret_cast<f16x4*>(p) = v; }
 template <> __device__ __forceinline__ void store4<bf16>(bf16* p, const float* o) {
-  uint2 v; v.x = (uint32_t)f_to_bf16(o[0]) | ((uint32_t)f_to_bf16(o[1]) << 16); v.y = (uint32_t)f_to_bf16(o[2]) | ((uint32_t)f_to_bf16(o[3]) << 16);
+  uint2 v; v.x = f2_to_bf16x2(o[0], o[1]); v.y = f2_to_bf16x2(o[2], o[3]);
   *reinterpret_cast<uint2*>(p) = v;
 }
 

@@ -264,7 +264,7 @@ __device__ __forceinline__ void fc_store_tile(uint16_t* tile, int pix, int h, co
       for (int e = 0; e < 4; ++e) x.hh[e] = (f16)v[e];
       w = x.u;
     } else {
-      w.x = (uint32_t)f_to_bf16(v[0]) | ((uint32_t)f_to_bf16(v[1]) << 16); w.y = (uint32_t)f_to_bf16(v[2]) | ((uint32_t)f_to_bf16(v[3]) << 16);
+      w.x = f2_to_bf16x2(v[0], v[1]); w.y = f2_to_bf16x2(v[2], v[3]);
     }
     *reinterpret_cast<uint2*>(tile + pix * 32 + ((g4 ^ ((pix >> 2) & 3)) * 8) + 4 * h) = w;
   }

@@ -15,14 +15,16 @@ typedef float  f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef short  s16x4 __attribute__((ext_vector_type(4)));
 typedef short  s16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ float bf16_to_f(uint16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-__device__ __forceinline__ uint16_t f_to_bf16(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // keep NaN a NaN
-  return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+// round-to-nearest-even through the hardware converter (v_cvt_pk_bf16_f32 on gfx950)
+__device__ __forceinline__ uint16_t f_to_bf16(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
+__device__ __forceinline__ uint32_t f2_to_bf16x2(float lo, float hi) {
+  bf16x2 v; v[0] = (__bf16)lo; v[1] = (__bf16)hi;
+  return __builtin_bit_cast(uint32_t, v);
 }
 
 template <typename T> struct ET;                       // element traits
@@ -74,7 +76,7 @@ template <> __device__ __forceinline__ V16 pack<f16>(const float* in) {
 template <> __device__ __forceinline__ V16 pack<bf16>(const float* in) {
   V16 v;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) v.w[i] = (uint32_t)f_to_bf16(in[2 * i]) | ((uint32_t)f_to_bf16(in[2 * i + 1]) << 16);
+  for (int i = 0; i < 4; ++i) v.w[i] = f2_to_bf16x2(in[2 * i], in[2 * i + 1]);
   return v;
 }
 __device__ __forceinline__ V16 zero16() { V16 v; v.w[0] = v.w[1] = v.w[2] = v.w[3] = 0; return v; }
