@@ -12,3 +12,9 @@ timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $O/sam
 cd $R
 find $O -name "*.csv" -size +3M -delete      # keep the stats / small counter files only (64 MiB merge cap)
 ls -la $O/*/* | head -40
+# default bench run (with the bounded cpu_baseline) -> JSON line for profiles/r1_final_bench.json
+timeout -k 10 500 python $R/bench.py > $O/default_bench.log 2>&1 && echo bench ok
+timeout -k 10 200 python $R/bench.py --flat-adamw --no-cpu-baseline --steps 20 --warmup 5 > $O/flat_bench.log 2>&1 && echo flat ok
+timeout -k 10 200 python $R/bench.py --recon wmse_msssim --members 1 --no-cpu-baseline --steps 20 --warmup 5 > $O/msssim_bench.log 2>&1 && echo ms ok
+timeout -k 10 200 python $R/bench.py --mode sample --steps 10 > $O/sample_bench.log 2>&1 && echo sample ok
+timeout -k 10 200 python $R/bench.py --mode sample --hr --steps 10 > $O/sample_hr_bench.log 2>&1 && echo samplehr ok
