@@ -51,6 +51,7 @@ struct GaussNet {
   std::vector<int> pool_before;                                            // 1 if a maxpool precedes conv i
   int64_t wmu = -1, bmu = -1, wls = -1, bls = -1;
   float *hbuf = nullptr, *mu = nullptr, *ls = nullptr, *dmu = nullptr, *dls = nullptr;
+  float* enc_inv = nullptr;            // f16: 1 / (device-chosen power-of-two scale of this encoder's backward), see launch_enc_rescale
   int lastB = 0;
 };
 
@@ -343,6 +344,7 @@ static int build_plan(pu_ctx* c) {
     g.hbuf = alloc_f32(c, (size_t)mb * cf_last);
     g.mu = alloc_f32(c, (size_t)mb * L); g.ls = alloc_f32(c, (size_t)mb * L);
     g.dmu = alloc_f32(c, (size_t)mb * L); g.dls = alloc_f32(c, (size_t)mb * L);
+    g.enc_inv = alloc_f32(c, 16);
   };
   build_gauss(c->prior, "prior", c->x_in, cf.input_channels, cin_pad);
   build_gauss(c->post, "posterior", c->xy_in, cf.input_channels + cf.num_classes, cxy_pad);
@@ -469,8 +471,10 @@ static int join2(pu_ctx* c, hipStream_t s, hipStream_t s2) {
 template <typename T> static int conv_bgrad(pu_ctx* c, TV dy, int B, float* d0, float* d1, hipStream_t s);
 // weight gradient (+ bias gradient d0/d1 = column sums of dy when d0 != null)
 template <typename T>
-static int conv_wgrad(pu_ctx* c, const ConvL& L, TV dy, TV in, int B, hipStream_t s, float* d0 = nullptr, float* d1 = nullptr) {
+static int conv_wgrad(pu_ctx* c, const ConvL& L, TV dy, TV in, int B, hipStream_t s, float* d0 = nullptr, float* d1 = nullptr,
+                      const float* inv_dev = nullptr) {
   WgradArgs a; memset(&a, 0, sizeof a);
+  a.inv_scale_dev = inv_dev;
   if (sizeof(T) == 2) { a.dbias0 = d0; a.dbias1 = d1; }
   else if (d0) { int r = conv_bgrad<T>(c, dy, B, d0, d1, s); if (r) return r; }
   a.dy = dy.p; a.dy_ld = dy.ld; a.Cout = L.cout; a.in = in.p; a.in_ld = in.ld; a.Cin = L.cin;
@@ -647,13 +651,18 @@ template <typename T>
 static int gauss_backward(pu_ctx* c, GaussNet& g, hipStream_t s) {
   int r; const int B = g.lastB, L = c->cfg.latent_dim;
   if (B <= 0) FAIL(PU_ERR_STATE, "Gaussian-encoder backward without a forward");
+  // f16: this sub-graph gets its own power-of-two scale, chosen ON THE DEVICE from the max-abs of its entry gradients.  The
+  // static loss scale is sized for the reconstruction gradient; the KL gradient entering here can be 10^6 times larger at
+  // initialisation (overflow) or, during the beta_1 = 0 warm-up, only the tiny reconstruction part remains (underflow).
+  const float* inv_dev = nullptr;
+  if (c->dt == PU_F16) { CKH(launch_enc_rescale(g.dmu, g.dls, B * L, 4096.f, g.enc_inv, s)); inv_dev = g.enc_inv; }
   TV lastg = with_b(g.outs.back().g, B);
   CKH(launch_heads_bwd<T>(with_b(g.outs.back().v, B), lastg, g.hbuf, P(c, g.wmu), P(c, g.wls), g.dmu, g.dls, L,
-                          G(c, g.wmu), G(c, g.bmu), G(c, g.wls), G(c, g.bls), c->inv_scale, s));
+                          G(c, g.wmu), G(c, g.bmu), G(c, g.wls), G(c, g.bls), c->inv_scale, s, inv_dev));
   for (int i = (int)g.convs.size() - 1; i >= 0; --i) {
     TV dy = with_b(g.outs[i].g, B);
     CKH(launch_relu_bwd<T>(with_b(g.outs[i].v, B), dy, s));
-    if ((r = conv_wgrad<T>(c, g.convs[i], g.outs[i].g, g.ins[i].v, B, s, G(c, g.convs[i].b_off), nullptr))) return r;
+    if ((r = conv_wgrad<T>(c, g.convs[i], g.outs[i].g, g.ins[i].v, B, s, G(c, g.convs[i].b_off), nullptr, inv_dev))) return r;
     if (i == 0) break;
     if ((r = conv_dgrad<T>(c, g.convs[i], g.outs[i].g, g.ins[i].g, B, 0, s))) return r;
     if (g.pool_before[i]) CKH(launch_maxpool_bwd<T>(with_b(g.outs[i - 1].v, B), with_b(g.ins[i].g, B), with_b(g.outs[i - 1].g, B), s));

@@ -889,9 +889,11 @@ __global__ __launch_bounds__(256) void heads_bwd_dx_kernel(TV dx, const float* _
   }
 }
 __global__ void heads_bwd_param_kernel(const float* __restrict__ hbuf, const float* __restrict__ dmu, const float* __restrict__ dls,
-                                       int B, int L, int C, float* dwmu, float* dbmu, float* dwls, float* dbls, float inv_scale) {
+                                       int B, int L, int C, float* dwmu, float* dbmu, float* dwls, float* dbls, float inv_scale,
+                                       const float* __restrict__ inv_dev) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= L * C) return;
+  if (inv_dev) inv_scale *= inv_dev[0];
   const int l = i / C, c = i % C;
   float a = 0.f, q = 0.f, sa = 0.f, sq = 0.f;
   for (int b = 0; b < B; ++b) {
@@ -902,13 +904,41 @@ __global__ void heads_bwd_param_kernel(const float* __restrict__ hbuf, const flo
   dwmu[i] += a * inv_scale; dwls[i] += q * inv_scale;
   if (c == 0) { dbmu[l] += sa * inv_scale; dbls[l] += sq * inv_scale; }
 }
+// one block: max-abs of the 2n entry gradients -> power-of-two factor bringing it into [target/2, target] -> rescale in place
+__global__ __launch_bounds__(256) void enc_rescale_kernel(float* __restrict__ dmu, float* __restrict__ dls, int n, float target, float* __restrict__ inv_out) {
+  __shared__ float red[4];
+  __shared__ float fac;
+  float mx = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) mx = fmaxf(mx, fmaxf(fabsf(dmu[i]), fabsf(dls[i])));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float f = 1.f;
+    if (mx > 0.f && isfinite(mx)) {
+      int e = (int)floorf(log2f(target / mx));
+      e = e < -60 ? -60 : (e > 60 ? 60 : e);
+      f = exp2f((float)e);
+    }
+    fac = f; inv_out[0] = 1.f / f;
+  }
+  __syncthreads();
+  const float f = fac;
+  for (int i = threadIdx.x; i < n; i += 256) { dmu[i] *= f; dls[i] *= f; }
+}
+hipError_t launch_enc_rescale(float* dmu, float* dls, int n, float target, float* inv_out, hipStream_t s) {
+  hipLaunchKernelGGL(enc_rescale_kernel, dim3(1), dim3(256), 0, s, dmu, dls, n, target, inv_out);
+  return hipGetLastError();
+}
 template <typename T>
 hipError_t launch_heads_bwd(TV xs, TV dx, const float* hbuf, const float* wmu, const float* wls, const float* dmu, const float* dls,
-                            int L, float* dwmu, float* dbmu, float* dwls, float* dbls, float inv_scale, hipStream_t s) {
+                            int L, float* dwmu, float* dbmu, float* dwls, float* dbls, float inv_scale, hipStream_t s, const float* inv_dev) {
   const long HW = (long)dx.H * dx.W;
   const int nchunk = (int)min((long)64, (HW * (dx.C / ET<T>::VEC) + 255) / 256);
   hipLaunchKernelGGL(heads_bwd_dx_kernel<T>, dim3(nchunk, dx.B), dim3(256), 0, s, dx, wmu, wls, dmu, dls, L, nchunk);
-  hipLaunchKernelGGL(heads_bwd_param_kernel, dim3(cdiv((long)L * dx.C, 256)), dim3(256), 0, s, hbuf, dmu, dls, dx.B, L, dx.C, dwmu, dbmu, dwls, dbls, inv_scale);
+  hipLaunchKernelGGL(heads_bwd_param_kernel, dim3(cdiv((long)L * dx.C, 256)), dim3(256), 0, s, hbuf, dmu, dls, dx.B, L, dx.C, dwmu, dbmu, dwls, dbls, inv_scale, inv_dev);
   (void)xs;
   return hipGetLastError();
 }
@@ -1109,7 +1139,7 @@ hipError_t launch_adamw_flat(float* p, const float* g, float* m, float* v, long 
   template hipError_t launch_heads_fwd<T>(TV, const float*, const float*, const float*, const float*, int, float*,   \
                                           float*, float*, hipStream_t);                                              \
   template hipError_t launch_heads_bwd<T>(TV, TV, const float*, const float*, const float*, const float*,            \
-                                          const float*, int, float*, float*, float*, float*, float, hipStream_t);
+                                          const float*, int, float*, float*, float*, float*, float, hipStream_t, const float*);
 PU_INST(float)
 PU_INST(f16)
 PU_INST(bf16)

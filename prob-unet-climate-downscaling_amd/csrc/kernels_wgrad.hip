@@ -216,8 +216,10 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad16_kernel(WgradArgs a) {
 // dw[co][ci][tap] += inv_scale * sum_s slab[s][tap][co][ci]   (fixed order -> reproducible)
 // block = 64 consecutive elements x 4 split lanes (coalesced 256-byte rows per split), LDS combine
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int split, int taps, int cout_pad, int cin_pad, int Cout, int Cin,
-                                                            float* __restrict__ dw, float inv_scale, float* db0, float* db1) {
+                                                            float* __restrict__ dw, float inv_scale, float* db0, float* db1,
+                                                            const float* __restrict__ inv_dev) {
   __shared__ float red[4][64];
+  if (inv_dev) inv_scale *= inv_dev[0];            // device-chosen scale of this sub-graph (latent encoders, f16)
   const long total = (long)taps * Cout * Cin;
   const long nwb = (total + 63) / 64;
   if (blockIdx.x >= nwb) {                       // bias rows: slab tail [split][cout_pad]
@@ -292,7 +294,7 @@ static hipError_t launch_wg16(const WgradArgs& a, hipStream_t s) {
   const long total = (long)TAPS * a.Cout * a.Cin;
   const unsigned nbias_blocks = a.dbias0 ? (unsigned)cdiv(a.Cout, 64) : 0u;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64) + nbias_blocks), dim3(256), 0, s, a.slab, split, TAPS,
-                     gy * WBCO, gz * BCI, a.Cout, a.Cin, a.dw, a.inv_scale, a.dbias0, a.dbias1);
+                     gy * WBCO, gz * BCI, a.Cout, a.Cin, a.dw, a.inv_scale, a.dbias0, a.dbias1, a.inv_scale_dev);
   return hipGetLastError();
 }
 

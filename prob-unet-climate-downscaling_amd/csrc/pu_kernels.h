@@ -32,6 +32,7 @@ struct WgradArgs {
   int B, H, W; int taps;
   float* slab; long slab_floats;                 // split-K partial slabs (16-bit path; required there)
   float inv_scale;                               // parameter gradients are multiplied by this (loss-scale removal)
+  const float* inv_scale_dev;                    // optional device float multiplied on top (sub-graph scale chosen on the device)
   float* dbias0; float* dbias1;                  // optional (16-bit path): bias gradient(s) = column sums of dy, ADDED into
 };
 struct PackDesc { long src_off; long dst_off; int Cout, Cin, taps, rows_pk, k_pk, mode; };   // mode: 0 fwd, 1 dgrad; +2 = fragment-major
@@ -93,9 +94,12 @@ template <typename T> hipError_t launch_bias_grad(TV dy, float* dbias0, float* d
 // h[b,c] = mean over pixels; mu = Wmu h + bmu; ls = Wls h + bls.  hbuf fp32 [B][C]
 template <typename T> hipError_t launch_heads_fwd(TV x, const float* wmu, const float* bmu, const float* wls, const float* bls,
                                                   int L, float* hbuf, float* mu, float* ls, hipStream_t);
+// f16 latent-encoder backward: rescale the entry gradients (dmu, dls; n values each) by a power of two so that their max-abs
+// lands in [target/2, target]; inv_out[0] = 1 / factor (multiplied into every parameter-gradient write of that sub-graph)
+hipError_t launch_enc_rescale(float* dmu, float* dls, int n, float target, float* inv_out, hipStream_t s);
 template <typename T> hipError_t launch_heads_bwd(TV x_shape, TV dx, const float* hbuf, const float* wmu, const float* wls,
                                                   const float* dmu, const float* dls, int L,
-                                                  float* dwmu, float* dbmu, float* dwls, float* dbls, float inv_scale, hipStream_t);
+                                                  float* dwmu, float* dbmu, float* dwls, float* dbls, float inv_scale, hipStream_t, const float* inv_dev = nullptr);
 struct LatentArgs {
   const float* mu_q; const float* ls_q; const float* mu_p; const float* ls_p;   // [B,L]
   const float* eps;            // [M,B,L]
