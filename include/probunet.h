@@ -114,6 +114,11 @@ int pu_elbo_fwd_bwd(pu_ctx*, const float* x, const float* target, const float* e
                     float beta0, float beta1, float beta2, float alpha, int train, uint64_t drop_seed,
                     int with_backward, float* out_scalars, float* out_kl, float* out_kl2, void* stream);
 
+/* Location / scale [B, L] of the prior (PU_PRIOR) or posterior (PU_POSTERIOR) computed by the LAST forward of that encoder
+ * (pu_elbo_fwd_bwd, pu_gauss_fwd or pu_sample): what the reference leaves behind in `self.prior_latent_space` /
+ * `self.posterior_latent_space` (prob_unet.py:214,220,241-242). scale = exp(log_sigma) + 1e-7 (prob_unet.py:84). */
+int pu_last_latent(pu_ctx*, int which, float* mu, float* sigma, int B, void* stream);
+
 /* ---- sampling (replaces n x model(x, training=False), train_prob_unet_model.py:244-247, and
  *      latent_exploration.py:119-129): U-Net + prior (or posterior if target given) ONCE, then n x Fcomb. ---- */
 /* eps [n,B,L]; out [B,n,Cout,H,W]; mu/sigma [B,L] nullable. */

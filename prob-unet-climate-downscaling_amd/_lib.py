@@ -69,6 +69,7 @@ def lib():
     L.pu_elbo_fwd_bwd.restype = i32
     L.pu_elbo_fwd_bwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, f32, f32, f32, f32, i32, u64, i32, vp, vp, vp, vp]
     L.pu_sample.restype = i32; L.pu_sample.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, vp, vp]
+    L.pu_last_latent.restype = i32; L.pu_last_latent.argtypes = [vp, i32, vp, vp, i32, vp]
     L.pu_sample_hr.restype = i32
     L.pu_sample_hr.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, f32, i32, f32, vp, vp, vp, vp]
     L.pu_set_recon_wmse_msssim.restype = i32; L.pu_set_recon_wmse_msssim.argtypes = [vp, f32, f32, f32, f32]

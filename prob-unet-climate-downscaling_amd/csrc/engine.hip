@@ -1000,6 +1000,16 @@ __global__ void export_mu_sigma_kernel(const float* mu, const float* ls, float* 
   if (i < n) { if (omu) omu[i] = mu[i]; if (osig) osig[i] = expf(ls[i]) + 1e-7f; }
 }
 
+int pu_last_latent(pu_ctx* c, int which, float* mu, float* sigma, int B, void* stream) {
+  if (!c || (!mu && !sigma)) return PU_ERR_INVALID;
+  GaussNet& g = which == PU_POSTERIOR ? c->post : c->prior;
+  if (g.lastB <= 0) FAIL(PU_ERR_STATE, "no forward of that latent encoder yet");
+  if (B != g.lastB) FAIL(PU_ERR_INVALID, "B=%d but the last forward of that encoder had %d samples", B, g.lastB);
+  const int n = B * c->cfg.latent_dim;
+  hipLaunchKernelGGL(export_mu_sigma_kernel, dim3(cdiv((long)n, 256)), dim3(256), 0, (hipStream_t)stream, g.mu, g.ls, mu, sigma, n);
+  return hipGetLastError() == hipSuccess ? PU_OK : PU_ERR_HIP;
+}
+
 static int sample_impl(pu_ctx* c, const float* x, const float* target, const float* eps, int B, int n, float* out, float* mu, float* sigma,
                        const float* lrinterp, const float* resid_std, float epsilon, int softplus, float softplus_c, void* stream) {
   if (!c || !x || !eps || !out) return PU_ERR_INVALID;

@@ -267,8 +267,8 @@ class ProbabilisticUNet(nn.Module):
         self.recon = recon
         self.dropout = float(dropout)
         self.sync_scalars = True          # reference returns python floats (.item()); set False to keep device scalars
-        self.prior_latent_space = None
-        self.posterior_latent_space = None
+        self._pls = None                  # prior_latent_space / posterior_latent_space: a distribution, None, or a pending
+        self._qls = None                  # fetch (int B) filled from the engine on first access after a fused elbo()
         self._want_batch, self._want_members = int(max_batch), int(max_members)
         self._ctx = None
         self._ctx_key = None
@@ -320,6 +320,34 @@ class ProbabilisticUNet(nn.Module):
             _init_reference_order(self)
 
     # ------------------------------------------------------------------ engine management
+    # side-effect attributes of the reference (prob_unet.py:214,220,241-242).  After the fused elbo() they are materialised
+    # lazily: the engine still holds (mu, log_sigma) of its last forward, nothing is copied unless somebody looks.
+    def _latent_dist(self, which, B):
+        dev = self._owner_device()
+        mu = torch.empty(B, self.latent_dim, device=dev, dtype=torch.float32); sg = torch.empty_like(mu)
+        L.check(L.lib().pu_last_latent(self._ctx, which, L.ptr(mu), L.ptr(sg), B, L.current_stream()), self._ctx, "pu_last_latent")
+        return Independent(Normal(loc=mu, scale=sg), 1)
+
+    @property
+    def prior_latent_space(self):
+        if isinstance(self._pls, int):
+            self._pls = self._latent_dist(L.PU_PRIOR, self._pls)
+        return self._pls
+
+    @prior_latent_space.setter
+    def prior_latent_space(self, v):
+        self._pls = v
+
+    @property
+    def posterior_latent_space(self):
+        if isinstance(self._qls, int):
+            self._qls = self._latent_dist(L.PU_POSTERIOR, self._qls)
+        return self._qls
+
+    @posterior_latent_space.setter
+    def posterior_latent_space(self, v):
+        self._qls = v
+
     def _cfg_struct(self, H, W, max_batch, max_members):
         cfg = L.PuConfig()
         cfg.input_channels, cfg.num_classes, cfg.latent_dim = self.input_channels, self.num_classes, self.latent_dim
@@ -626,6 +654,7 @@ class ProbabilisticUNet(nn.Module):
             total = _DeliverGrads.apply(total, self._anchor_t(), self, 0, self._nparams)
         recon = scal[L.PU_S_RECON]
         self._last_scalars = scal
+        self._pls, self._qls = int(B), int(B)          # prob_unet.py:241-242: both latent spaces are left behind by elbo()
         if self.sync_scalars:
             host = scal.tolist()                                  # one device->host sync for every logged scalar
             recon_list = [host[L.PU_S_RECON]]

@@ -225,3 +225,22 @@ def test_short_training_run_f16_tracks_f32_and_loss_decreases():
     a, b = np.array(curves["f32"]), np.array(curves["f16"])
     assert a[-1] < 0.8 * a[0], (a[0], a[-1])
     assert np.all(np.abs(a - b) <= 0.05 * np.abs(a) + 1e-3), np.max(np.abs(a - b) / np.abs(a))
+
+
+def test_latent_space_attributes_after_fused_elbo():
+    """prob_unet.py:241-242: elbo() leaves prior_latent_space / posterior_latent_space behind; here they are fetched lazily
+    from the engine and must equal what the sub-modules return for the same inputs (and reproduce the returned KL)."""
+    m, cfg, P = _small_model("afcrps", H=32)
+    m.eval()
+    x, y = make_fields(2, 2, 1, 32, 32, seed=8)
+    x, y = x.to(DEV), y.to(DEV)
+    assert m.prior_latent_space is None and m.posterior_latent_space is None
+    with torch.no_grad():
+        _, _, kl = m.elbo(x, y, None, M=2, eps=make_eps(2, 2, 4).to(DEV))
+        p, q = m.prior_latent_space, m.posterior_latent_space
+        p2, q2 = m.prior(x), m.posterior(x, y)
+    assert_close(p.base_dist.loc.cpu(), p2.base_dist.loc.cpu(), what="prior loc"); assert_close(p.base_dist.scale.cpu(), p2.base_dist.scale.cpu(), what="prior scale")
+    assert_close(q.base_dist.loc.cpu(), q2.base_dist.loc.cpu(), what="post loc"); assert_close(q.base_dist.scale.cpu(), q2.base_dist.scale.cpu(), what="post scale")
+    assert_close(torch.distributions.kl.kl_divergence(q, p).cpu(), kl.cpu(), what="kl from the attributes")
+    m.prior_latent_space = "user value"                      # plain attribute semantics are kept
+    assert m.prior_latent_space == "user value"
