@@ -165,7 +165,10 @@ def main():
     ap.add_argument("--members", type=int, default=CFG3["M"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-optimizer", action="store_true", help="time ELBO fwd+bwd only (diagnostic; not the reported metric)")
-    ap.add_argument("--flat-adamw", action="store_true", help="use the fused flat AdamW (pu_adamw_step) instead of torch.optim.AdamW")
+    ap.add_argument("--torch-adamw", action="store_true",
+                    help="use torch.optim.AdamW(fused=True) over the parameter views instead of the engine's flat AdamW (pu_adamw_step, the default; "
+                         "same update rule, pinned against the reference's AdamW step in tests/test_gpu_model.py)")
+    ap.add_argument("--flat-adamw", action="store_true", help=argparse.SUPPRESS)      # former spelling of the default
     ap.add_argument("--mode", default="train", choices=["train", "sample"],
                     help="sample = BASELINE config 5: prior samples/s, 64 samples per lo-res input (U-Net + prior once, 64 x Fcomb)")
     ap.add_argument("--samples", type=int, default=64)
@@ -196,7 +199,8 @@ def main():
     torch.manual_seed(1234 + rank)                   # rank-offset reparameterisation noise (dropout seeds are rank-offset inside the model)
     if world > 1:
         model.enable_data_parallel()
-    if args.flat_adamw:
+    flat = not args.torch_adamw
+    if flat:
         import probunet_amd as pa
         opt = pa.FlatAdamW(model, lr=1e-4)
     else:
@@ -272,7 +276,7 @@ def main():
                scaling="weak", vs_baseline=None, dtype=args.dtype, data="synthetic",
                config=dict(workload=f"cfg3: 4->1 planes, 256x256, latent 12, depth-5 U-Net, {cfg['batch']} field pairs per GPU, "
                                     f"{'afCRPS' if args.recon == 'afcrps' else args.recon}-ELBO M={cfg['M']} fwd+bwd, train mode (dropout 0.1)"
-                                    + ("" if args.no_optimizer else (" + fused flat AdamW step" if args.flat_adamw else " + AdamW step")) + (" + RCCL grad all-reduce" if world > 1 else ""),
+                                    + ("" if args.no_optimizer else (" + AdamW step (fused flat kernel)" if flat else " + torch AdamW step")) + (" + RCCL grad all-reduce" if world > 1 else ""),
                            global_batch=world * cfg["batch"], parallelism=f"dp{world}",
                            elbo_fwd_bwd_tflop_per_step=round(3 * fwd_flops / 1e12, 3),
                            model_tflops=round(3 * fwd_flops * world / (elapsed / args.steps) / 1e12, 2), final_loss=loss_val),
