@@ -759,7 +759,7 @@ int pu_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_
 }
 int pu_set_overlap(pu_ctx* c, int on) {
   if (!c) return PU_ERR_INVALID;
-  c->use_side = on != 0 && c->side && c->side2 && c->dt != PU_F32 && !getenv("PU_NO_SIDE_STREAM");
+  c->use_side = on != 0 && c->side && c->side2 && c->dt != PU_F32 && !getenv("PU_NO_SIDE_STREAM");      // (not on a hot path)
   return PU_OK;
 }
 int pu_profile_collect(pu_prof_entry* out, int max_entries) {

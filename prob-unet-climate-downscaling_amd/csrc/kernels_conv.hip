@@ -331,7 +331,6 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3_kernel(ConvArgs a) {
   constexpr int NT = 64 * WM * WN;
   constexpr int BM = TH * TW;
   constexpr int NTM = BM / (32 * WM);
-  constexpr int BN = 32 * WN;
   constexpr int TAPS = KS * KS, PADP = KS / 2;
   constexpr int IH = TH + 2 * PADP, IW = TW + 2 * PADP;
   constexpr int KCP = KC + M::PAD;
@@ -777,7 +776,8 @@ static hipError_t launch_conv3(const ConvArgs& a, hipStream_t s) {
     // 148 KB-LDS persistent configuration by ~7 %
     if (a.cin_pk == 2 * KC && a.Cout > 32 && a.Cout <= 64 && a.W % 32 == 0 && a.H % 4 == 0)
       return launch_conv3_cfg<T, KS, 4, 32, 2, 2>(a, s);
-    if (a.cin_pk <= 2 * KC && !getenv("PU_NO_CONV3P")) {       // short-K layers: persistent, weight-resident variant
+    static const bool no_conv3p = getenv("PU_NO_CONV3P") != nullptr;       // diagnostic switch, read once
+    if (a.cin_pk <= 2 * KC && !no_conv3p) {       // short-K layers: persistent, weight-resident variant
       hipError_t e = hipErrorNotSupported;
       if (a.W % 32 == 0 && a.H % 8 == 0) e = launch_conv3p<T, KS, 8, 32>(a, s);
       else if (a.W % 16 == 0 && a.H % 16 == 0) e = launch_conv3p<T, KS, 16, 16>(a, s);

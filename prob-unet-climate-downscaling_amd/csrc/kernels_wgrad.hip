@@ -301,9 +301,10 @@ static hipError_t launch_wg16(const WgradArgs& a, hipStream_t s) {
 template <typename T, int KS>
 static hipError_t launch_wg16_ks(const WgradArgs& a, hipStream_t s) {
   const bool wide = a.Cin > 32;
-  if (a.W % 32 == 0 && a.H % 8 == 0 && wide && getenv("PU_WG_BIG")) return launch_wg16<T, KS, 8, 32, 64>(a, s);   // 256-pixel K tiles: +4 % alone,
+  static const bool wg_big = getenv("PU_WG_BIG") != nullptr, wg_4w = getenv("PU_WG_4W") != nullptr;     // diagnostic switches, read once
+  if (a.W % 32 == 0 && a.H % 8 == 0 && wide && wg_big) return launch_wg16<T, KS, 8, 32, 64>(a, s);   // 256-pixel K tiles: +4 % alone,
                                                                                             // but 152 KB LDS blocks co-residency with conv3
-  if (a.W % 32 == 0 && a.H % 4 == 0) return wide ? (getenv("PU_WG_4W") ? launch_wg16<T, KS, 4, 32, 64>(a, s) : launch_wg16<T, KS, 4, 32, 64, 8>(a, s)) : launch_wg16<T, KS, 4, 32, 32>(a, s);
+  if (a.W % 32 == 0 && a.H % 4 == 0) return wide ? (wg_4w ? launch_wg16<T, KS, 4, 32, 64>(a, s) : launch_wg16<T, KS, 4, 32, 64, 8>(a, s)) : launch_wg16<T, KS, 4, 32, 32>(a, s);
   if (a.W % 16 == 0 && a.H % 8 == 0) return wide ? launch_wg16<T, KS, 8, 16, 64>(a, s) : launch_wg16<T, KS, 8, 16, 32>(a, s);
   if (a.W % 8 == 0 && a.H % 8 == 0) return wide ? launch_wg16<T, KS, 8, 8, 64>(a, s) : launch_wg16<T, KS, 8, 8, 32>(a, s);
   return hipErrorInvalidValue;
