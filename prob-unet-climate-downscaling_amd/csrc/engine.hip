@@ -527,8 +527,10 @@ static int gn_fwd(pu_ctx* c, const GNL& n, TV x, TV y, int B, int train, uint64_
   return PU_OK;
 }
 template <typename T>
-static int gn_bwd(pu_ctx* c, const GNL& n, TV x, TV y, TV dy, TV dx, int accumulate, int B, int train, uint64_t seed, hipStream_t s) {
+static int gn_bwd(pu_ctx* c, const GNL& n, TV x, TV y, TV dy, TV dx, int accumulate, int B, int train, uint64_t seed, hipStream_t s,
+                  const TV* add = nullptr) {
   GNBwdArgs a; memset(&a, 0, sizeof a);
+  if (add && n.resample == RS_NONE) a.add = with_b(*add, B);
   a.f = gn_args(c, n, x, y, B, train, seed);
   a.dy = with_b(dy, B);
   a.dv = with_b(x, B); a.dv.p = c->dv_scratch.p; a.dv.ld = x.C;
@@ -588,7 +590,8 @@ static int block_bwd(pu_ctx* c, Block& b, int B, int train, uint64_t seed, bool 
     }
   } else if (need_dx) {
     if (b.skip == SK_RESAMPLE) CKH(launch_resample_bwd<T>(with_b(dout, B), with_b(b.x.g, B), b.down ? RS_DOWN : RS_UP, take_acc(c, b.x), s));
-    else CKH(launch_add<T>(with_b(dout, B), with_b(b.x.g, B), take_acc(c, b.x), s));
+    else if (b.n0.resample != RS_NONE || sizeof(T) == 4) CKH(launch_add<T>(with_b(dout, B), with_b(b.x.g, B), take_acc(c, b.x), s));
+    // else (identity skip, 16-bit engines): dout is added inside the pass 2 of norm0's backward below
   }
   // norm1 (+scale/shift, dropout) -> c0.g
   if ((r = gn_bwd<T>(c, b.n1, b.c0.v, b.h1.v, b.h1.g, b.c0.g, 0, B, train, seed, s))) return r;
@@ -599,7 +602,8 @@ static int block_bwd(pu_ctx* c, Block& b, int B, int train, uint64_t seed, bool 
   TV dx = b.x.g; int acc = 0;
   if (need_dx) acc = take_acc(c, b.x);
   else { dx = with_b(b.x.v, B); dx.p = c->dv_scratch.p; dx.ld = b.x.v.C; }      // never happens for blocks (x always needs grad)
-  return gn_bwd<T>(c, b.n0, b.x.v, b.a0.v, b.a0.g, dx, acc, B, train, seed, s);
+  const bool fold_skip = need_dx && b.skip == SK_IDENTITY && b.n0.resample == RS_NONE && sizeof(T) != 4;
+  return gn_bwd<T>(c, b.n0, b.x.v, b.a0.v, b.a0.g, dx, acc, B, train, seed, s, fold_skip ? &dout : nullptr);
 }
 
 template <typename T>

@@ -552,7 +552,8 @@ __global__ __launch_bounds__(256) void gn_bwd_pass2_kernel(GNBwdArgs a) {
     const T* dyp = reinterpret_cast<const T*>(a.dy.p);
     const uint32_t dkey = drop_key(f.drop_seed, f.drop_stream), dthr = drop_thr16(keep);
     for (long p = p0 + pl; p < p1; p += (long)PL * U) {
-      V16 rx[U], rd[U], ro[U];
+      V16 rx[U], rd[U], ro[U], ra[U];
+      const T* addp = reinterpret_cast<const T*>(a.add.p);
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const long pp = p + (long)u * PL;
@@ -560,6 +561,7 @@ __global__ __launch_bounds__(256) void gn_bwd_pass2_kernel(GNBwdArgs a) {
         rx[u] = ldv<T>(xp + bp * f.x.ld + cv * VEC);
         rd[u] = ldv<T>(dyp + bp * a.dy.ld + cv * VEC);
         if (a.accumulate) ro[u] = ldv<T>(dxp + bp * a.dx.ld + cv * VEC);
+        if (addp) ra[u] = ldv<T>(addp + bp * a.add.ld + cv * VEC);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -580,6 +582,11 @@ __global__ __launch_bounds__(256) void gn_bwd_pass2_kernel(GNBwdArgs a) {
           else {
 #pragma unroll
             for (int e = 0; e < VEC; ++e) o[e] = 0.f;
+          }
+          if (addp) {
+            float av[VEC]; unpack<T>(ra[u], av);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) o[e] += av[e];
           }
 #pragma unroll
           for (int e = 0; e < VEC; ++e) {
@@ -617,6 +624,7 @@ hipError_t launch_gn_bwd(const GNBwdArgs& a0, hipStream_t s) {
     GNBwdArgs a = a0;
     a.f = gn_sub(a0.f, b0, nb, sizeof(T));
     a.dy = tv_batch(a0.dy, b0, nb, sizeof(T)); a.dx = tv_batch(a0.dx, b0, nb, sizeof(T)); a.dv = tv_batch(a0.dv, b0, nb, sizeof(T));
+    a.add = tv_batch(a0.add, b0, nb, sizeof(T));
     a.part2 = a0.part2 + (size_t)b0 * a0.f.nchunk * a0.f.x.C * 2; a.coef2 = a0.coef2 + (size_t)b0 * a0.f.x.C * 3;
     const GNArgs& f = a.f;
     dim3 g1(f.nchunk, f.x.B);
@@ -991,17 +999,19 @@ __global__ void latent_bwd_kernel(LatentBwdArgs a) {
     float dmq = 0.f, dsq = 0.f;
     if (a.dz)
       for (int m = 0; m < f.M; ++m) { const float g = a.dz[(long)m * BL + i]; dmq += g; dsq += g * f.eps[(long)m * BL + i]; }
-    const float d = mq - mp, isp2 = 1.f / (sp * sp);
     const float k1 = a.beta1 * invB, k2 = a.beta2 * invB;
-    // d/dsq = (sq^2 - sp^2) / (sq sp^2), d/dsp = (sp^2 - sq^2 - d^2) / sp^3: written with (a-b)(a+b) so that q ~ p
-    // does not cancel catastrophically in fp32
-    const float dif = (sq - sp) * (sq + sp);
-    dmq += k1 * d * isp2 + k2 * mq;
-    dsq += k1 * dif * isp2 / sq + k2 * (sq - 1.f) * (sq + 1.f) / sq;
-    const float dmp = -k1 * d * isp2;
-    const float dsp = k1 * (-dif - d * d) * isp2 / sp;
+    // d/dsq = (sq^2 - sp^2) / (sq sp^2), d/dsp = (sp^2 - sq^2 - d^2) / sp^3, written in RATIOS to sp: (a-b)(a+b) keeps q ~ p from
+    // cancelling in fp32, and nothing is squared or cubed on its own, so sigma_p ~ 1e21 (a prior log-sigma of 49, reached in
+    // tools/train_demo.py when beta_1 is switched on) gives small finite gradients instead of the inf * 0 = NaN of the direct
+    // form (torch's own KL backward overflows there as well)
+    const float t = (mq - mp) / sp;                               // (mu_q - mu_p) / sigma_p
+    const float r2m1 = ((sq - sp) / sp) * ((sq + sp) / sp);       // (sigma_q / sigma_p)^2 - 1
+    dmq += k1 * t / sp;
+    dsq += k1 * r2m1 / sq;
+    if (k2 != 0.f) { dmq += k2 * mq; dsq += k2 * (sq - 1.f) * (sq + 1.f) / sq; }
+    const float dmp = -k1 * t / sp;
     a.dmu_q[i] = dmq; a.dls_q[i] = dsq * eq;
-    a.dmu_p[i] = dmp; a.dls_p[i] = dsp * ep;
+    a.dmu_p[i] = dmp; a.dls_p[i] = k1 * (-r2m1 - t * t) * (ep / sp);
   }
 }
 hipError_t launch_latent_bwd(const LatentBwdArgs& a, hipStream_t s) {

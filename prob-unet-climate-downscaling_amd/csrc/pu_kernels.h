@@ -74,6 +74,8 @@ struct GNBwdArgs {
   TV dy;                      // grad wrt y (resampled geometry)
   TV dv;                      // scratch [B,H,W,C] (x geometry) for the pre-activation gradient
   TV dx; int accumulate;      // grad wrt x
+  TV add;                     // optional extra addend of dx (same geometry; p == null: none): the identity-skip gradient of a block,
+                              // folded into pass 2 instead of a separate add kernel (resample == 0 only)
   float* dgamma; float* dbeta; float* dscale; float* dshift;   // fp32 [C], ADDED into (nullable scale/shift)
   float* part2;               // [B][nchunk][C][2]
   float inv_scale;            // parameter gradients are multiplied by this
