@@ -244,3 +244,21 @@ def test_latent_space_attributes_after_fused_elbo():
     assert_close(torch.distributions.kl.kl_divergence(q, p).cpu(), kl.cpu(), what="kl from the attributes")
     m.prior_latent_space = "user value"                      # plain attribute semantics are kept
     assert m.prior_latent_space == "user value"
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_kl_gradients_stay_finite_for_extreme_prior_sigma(dtype):
+    """A prior log-sigma of 50 (sigma_p ~ 5e21; reached by Adam in tools/train_demo.py) squares to inf in fp32: the direct KL
+    derivative forms give inf * 0 = NaN there (torch's included).  The engine evaluates them in ratios to sigma_p:
+    d KL / d log sigma_p -> 1 - (sigma_q/sigma_p)^2 - ((mu_q-mu_p)/sigma_p)^2 -> 1, so the bias gradient is beta_1 exactly."""
+    m, cfg, P = _small_model("afcrps", dtype=dtype, H=32)
+    m.train(); m.dropout = 0.0
+    with torch.no_grad():
+        m.prior.conv_log_sigma.bias.fill_(50.0)
+    x, y = make_fields(2, 2, 1, 32, 32, seed=12)
+    total, _, kl = m.elbo(x.to(DEV), y.to(DEV), None, M=2, eps=make_eps(2, 2, 4).to(DEV))
+    total.backward()
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+    assert float(kl.min()) > 4 * 45.0          # 4 latent dims x log(sigma_p / sigma_q) ~ 50 (inf if (sigma_q/sigma_p)^2 underflows, as in torch)
+    g = m.prior.conv_log_sigma.bias.grad.cpu()
+    assert_close(g, torch.full_like(g, 1.3), rtol=1e-3, atol=1e-4, what="d total / d prior log-sigma bias = beta_1")
