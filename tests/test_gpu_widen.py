@@ -262,3 +262,23 @@ def test_kl_gradients_stay_finite_for_extreme_prior_sigma(dtype):
     assert float(kl.min()) > 4 * 45.0          # 4 latent dims x log(sigma_p / sigma_q) ~ 50 (inf if (sigma_q/sigma_p)^2 underflows, as in torch)
     g = m.prior.conv_log_sigma.bias.grad.cpu()
     assert_close(g, torch.full_like(g, 1.3), rtol=1e-3, atol=1e-4, what="d total / d prior log-sigma bias = beta_1")
+
+
+def test_ensemble_size_15_as_in_main_py():
+    """main.py:133 trains with ensemble_size = 15 (the fused afCRPS kernel keeps up to 16 members in registers): fp32 engine vs
+    the oracle, loss / KL / parameter gradients."""
+    m, cfg, P = _small_model("afcrps", H=32)
+    m.train(); m.dropout = 0.0
+    x, y = make_fields(2, 2, 1, 32, 32, seed=14); eps = make_eps(15, 2, 4)
+    total, recon, kl = m.elbo(x.to(DEV), y.to(DEV), None, M=15, eps=eps.to(DEV))
+    total.backward()
+    r, og = O.elbo_with_grads(P, cfg, x, y, eps, beta0=0.7, beta1=1.3)
+    assert_close(total.detach().cpu(), r["total"], what="total"); assert_close(recon[0], r["recon"], what="afcrps M=15"); assert_close(kl.cpu(), r["kl"], what="kl")
+    rels = []
+    for k, p in m.named_parameters():
+        v = og[k]
+        if float(v.norm()) < 1e-7: continue
+        rels.append(float((p.grad.detach().cpu().double() - v.double()).norm() / v.double().norm()))
+    assert max(rels) < 2e-2 and float(np.median(rels)) < 2e-3, (max(rels), float(np.median(rels)))
+    with pytest.raises(pa._lib.ProbUNetLibraryError):
+        m.elbo(x.to(DEV), y.to(DEV), None, M=17)
