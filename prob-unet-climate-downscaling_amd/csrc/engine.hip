@@ -914,7 +914,7 @@ int pu_elbo_fwd_bwd(pu_ctx* c, const float* x, const float* target, const float*
   int r; if ((r = check_B(c, B))) return r;
   if (M < 1 || M > c->cfg.max_members) FAIL(PU_ERR_INVALID, "M=%d outside [1, max_members=%d]", M, c->cfg.max_members);
   if (recon_kind == PU_RECON_AFCRPS && M < 2) FAIL(PU_ERR_INVALID, "M must be at least 2 to compute afCRPS but got M=%d", M);
-  if (recon_kind == PU_RECON_AFCRPS && M > 16) FAIL(PU_ERR_INVALID, "M=%d > 16 unsupported by the fused afCRPS kernel", M);
+  if (recon_kind == PU_RECON_AFCRPS && M > 32) FAIL(PU_ERR_INVALID, "M=%d > 32 unsupported by the fused afCRPS kernel", M);
   if (recon_kind != PU_RECON_AFCRPS && recon_kind != PU_RECON_L1 && recon_kind != PU_RECON_WMSE_MSSSIM) FAIL(PU_ERR_INVALID, "unknown recon kind %d", recon_kind);
   const bool msssim = recon_kind == PU_RECON_WMSE_MSSSIM;
   if (msssim) {

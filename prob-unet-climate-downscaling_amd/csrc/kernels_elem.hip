@@ -1022,8 +1022,7 @@ hipError_t launch_latent_bwd(const LatentBwdArgs& a, hipStream_t s) {
 // ------------------------------------------------------------------ reconstruction loss (afCRPS pair form / L1)
 // afCRPS (prob_unet_utils.py:171-234):  per element  [(M-1) sum_j |xj-y| - (1-e) sum_{j<k} |xj-xk|] / (M (M-1) C HW), mean over B
 // d/dxj = [(M-1) sgn(xj-y) - (1-e) sum_{k!=j} sgn(xj-xk)] / (B M (M-1) C HW)
-constexpr int MAXM = 16;
-template <int KIND>
+template <int KIND, int MAXM>
 __global__ __launch_bounds__(256) void recon_kernel(const float* __restrict__ preds, const float* __restrict__ target, float* __restrict__ dpred,
                                                     float* scalars, int B, int M, int C, long HW, float alpha, float gscale) {
   __shared__ float red[256];
@@ -1079,8 +1078,10 @@ hipError_t launch_recon(int kind, const float* preds, const float* target, float
                         float alpha, float gscale, hipStream_t s) {
   const long total = (long)B * C * HW;
   const unsigned g = (unsigned)min((long)2048, (total + 255) / 256);
-  if (kind == PU_RECON_AFCRPS) hipLaunchKernelGGL(recon_kernel<PU_RECON_AFCRPS>, dim3(g), dim3(256), 0, s, preds, target, dpred, scalars, B, M, C, HW, alpha, gscale);
-  else hipLaunchKernelGGL(recon_kernel<PU_RECON_L1>, dim3(g), dim3(256), 0, s, preds, target, dpred, scalars, B, M, C, HW, alpha, gscale);
+  if (kind == PU_RECON_AFCRPS && M > 32) return hipErrorInvalidValue;
+  if (kind == PU_RECON_AFCRPS && M > 16) hipLaunchKernelGGL((recon_kernel<PU_RECON_AFCRPS, 32>), dim3(g), dim3(256), 0, s, preds, target, dpred, scalars, B, M, C, HW, alpha, gscale);
+  else if (kind == PU_RECON_AFCRPS) hipLaunchKernelGGL((recon_kernel<PU_RECON_AFCRPS, 16>), dim3(g), dim3(256), 0, s, preds, target, dpred, scalars, B, M, C, HW, alpha, gscale);
+  else hipLaunchKernelGGL((recon_kernel<PU_RECON_L1, 16>), dim3(g), dim3(256), 0, s, preds, target, dpred, scalars, B, M, C, HW, alpha, gscale);
   return hipGetLastError();
 }
 __global__ void finish_scalars_kernel(float* sc, float beta0, float beta1, float beta2, int with_kl2) {
