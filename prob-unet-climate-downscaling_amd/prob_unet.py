@@ -316,6 +316,16 @@ class ProbabilisticUNet(nn.Module):
             offs = [(off, int(np.prod(shape))) for name, shape, off, is_buf in table if not is_buf and name.startswith(pre + ".")]
             self._ranges[pre] = (min(o for o, _ in offs), max(o + n for o, n in offs))
         self._nparams = max(hi for _, hi in self._ranges.values())
+        # the metadata scripts read off the leaf modules (latent_exploration.py:296: `model.fcomb.layers[0].in_channels`)
+        for mod in self.modules():
+            w = mod._parameters.get("weight") if hasattr(mod, "_parameters") else None
+            if w is not None and w.dim() == 4:
+                mod.out_channels, mod.in_channels = int(w.shape[0]), int(w.shape[1])
+                mod.kernel_size = (int(w.shape[2]), int(w.shape[3])); mod.stride = (1, 1); mod.padding = (int(w.shape[2]) // 2, int(w.shape[3]) // 2)
+            elif w is not None and w.dim() == 2:
+                mod.out_features, mod.in_features = int(w.shape[0]), int(w.shape[1])
+            elif w is not None and w.dim() == 1:
+                mod.num_channels = int(w.shape[0])
         if init:
             _init_reference_order(self)
 

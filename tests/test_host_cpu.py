@@ -181,3 +181,14 @@ def test_data_module_has_no_cpu_fallback():
         pa.data.lrinterp_to_residuals(torch.zeros(1, 1, 8, 8), 2, torch.zeros(1, 8, 8), torch.ones(1, 8, 8))
     with pytest.raises(ValueError):
         pa.ProbabilisticUNet(1, 1, 2, [8], 8, [1], 1.0, 1.0, 0.0, recon="ssim")
+
+
+def test_leaf_module_metadata_used_by_the_exploration_scripts():
+    """latent_exploration.py:296 / latent_exploration_posterior.py:200-202: `conv0 = model.fcomb.layers[0]; conv0.in_channels -
+    model.latent_dim` must give the feature width."""
+    import probunet_amd as pa
+    m = pa.ProbabilisticUNet(4, 1, 6, [32, 64], 32, [1, 2], 1.0, 1.0, 0.0)
+    conv0 = m.fcomb.layers[0]
+    assert conv0.in_channels - m.latent_dim == 32 and conv0.out_channels == 32 and conv0.kernel_size == (1, 1)
+    assert m.prior.encoder[0].in_channels == 4 and m.posterior.encoder[0].in_channels == 5 and m.prior.encoder[0].kernel_size == (3, 3)
+    assert m.prior.conv_mu.out_channels == 6 and m.unet.out_conv.out_channels == 32
