@@ -398,7 +398,8 @@ __global__ __launch_bounds__(256) void fcomb_bwd16_kernel(FcombBwdArgs a, const 
   // transposed-read lane roles
   const int g = l >> 4, q = (l & 15) >> 2, p = l & 3;
   const int nchunks = (int)((HW + CHP - 1) / CHP);
-  for (int i = tid; i < f.M * 32; i += 256) zbs[i] = zb[((long)(i >> 5) * f.B + b) * 32 + (i & 31)];
+  float* dzs = zbs + f.M * 32;                                      // [M][32]: this block's share of d(loss)/d(zb), flushed once at the end
+  for (int i = tid; i < f.M * 32; i += 256) { zbs[i] = zb[((long)(i >> 5) * f.B + b) * 32 + (i & 31)]; dzs[i] = 0.f; }
   __syncthreads();
   // dout of the next member is fetched while the current one is processed (HBM latency off the dependent chain).  Compact
   // form for Cout <= 4 (rows 0..3 live in the h == 0 half of both layouts); wider outputs load in place.
@@ -407,6 +408,17 @@ __global__ __launch_bounds__(256) void fcomb_bwd16_kernel(FcombBwdArgs a, const 
 #pragma unroll
     for (int e = 0; e < 4; ++e) dn[e] = (valid && small_co && h == 0 && e < f.Cout) ? a.dout[(((long)b * f.M + m) * f.Cout + e) * HW + pix] : 0.f;
   };
+  // the feature rows of the NEXT chunk are fetched while the members of the current one are processed
+  V16 nxf[2];
+  auto load_feat = [&](int ch, V16* out) {
+    const long pix = (long)ch * CHP + wave * 32 + j;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      out[s] = zero16();
+      if (ch < nchunks && pix < HW) out[s] = *reinterpret_cast<const V16*>(fp + pix * f.feat.ld + 16 * s + 8 * h);
+    }
+  };
+  load_feat(blockIdx.x, nxf);
   for (int ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
     // ---- per-wave: two 32-pixel column tiles; feat fragments and the shared pre-activation
     f32x16 pre, dfe;
@@ -420,8 +432,7 @@ __global__ __launch_bounds__(256) void fcomb_bwd16_kernel(FcombBwdArgs a, const 
       typename M::Frag fb[2];
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
-        union { V16 v; typename M::Frag fr; } x; x.v = zero16();
-        if (valid) x.v = *reinterpret_cast<const V16*>(fp + pix * f.feat.ld + 16 * s + 8 * h);
+        union { V16 v; typename M::Frag fr; } x; x.v = nxf[s];
         fb[s] = x.fr;
         // feat tile: channels 16 s + 8 h .. +7 -> 16-byte chunk (2 s + h), swizzled
         *reinterpret_cast<V16*>(tiles + 5 * TS + lp * 32 + (((2 * s + h) ^ ((lp >> 2) & 3)) * 8)) = x.v;
@@ -431,6 +442,7 @@ __global__ __launch_bounds__(256) void fcomb_bwd16_kernel(FcombBwdArgs a, const 
       pre = M::mfma(w.w0n[0], fb[0], pre);
       pre = M::mfma(w.w0n[1], fb[1], pre);
     }
+    load_feat(ch + gridDim.x, nxf);
     float dn[4];
     load_dout4(0, pix, valid, dn);
     for (int m = 0; m < f.M; ++m) {
@@ -515,9 +527,11 @@ __global__ __launch_bounds__(256) void fcomb_bwd16_kernel(FcombBwdArgs a, const 
         fr = fc_tr_frag<typename M::Frag>(tiles + 5 * TS + o0, tiles + 5 * TS + o1);     // feat
         aw[0] = M::mfma(fl, fr, aw[0]); az = M::mfma(fl, ones, az);
       }
+      // LDS adds: global atomics here (16 per wave and member, all blocks of a sample on the same 32 addresses) sat in vmcnt in
+      // front of the next dout / feat loads
       if (j == 0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) atomicAdd(dzb + ((long)m * f.B + b) * 32 + fc_row(r, h), az[r]);
+        for (int r = 0; r < 16; ++r) atomicAdd(&dzs[m * 32 + fc_row(r, h)], az[r]);
       }
     }
     if (a.dfeat.p) {
@@ -539,6 +553,8 @@ __global__ __launch_bounds__(256) void fcomb_bwd16_kernel(FcombBwdArgs a, const 
       }
     }
   }
+  __syncthreads();
+  for (int i = tid; i < f.M * 32; i += 256) atomicAdd(dzb + ((long)(i >> 5) * f.B + b) * 32 + (i & 31), dzs[i]);
   // ---- flush: D[row = o][col = c]; lane owns column j and rows fc_row(r, h)
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
@@ -633,12 +649,12 @@ hipError_t launch_fcomb_bwd(const FcombBwdArgs& a, hipStream_t s) {
     if constexpr (sizeof(T) == 2) {
       static bool attr16 = false;
       if (!attr16) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(fcomb_bwd16_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 128 * 32 * 2 + 256 * 32 * 4);
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(fcomb_bwd16_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 128 * 32 * 2 + 2 * 256 * 32 * 4);
         if (e != hipSuccess) return e;
         attr16 = true;
       }
       dim3 grid16((unsigned)min((long)24, (HW + 127) / 128), f.B);
-      hipLaunchKernelGGL((fcomb_bwd16_kernel<T>), grid16, dim3(256), 6 * 128 * 32 * 2 + (size_t)f.M * 32 * 4, s, a, zb, dzb);
+      hipLaunchKernelGGL((fcomb_bwd16_kernel<T>), grid16, dim3(256), 6 * 128 * 32 * 2 + (size_t)2 * f.M * 32 * 4, s, a, zb, dzb);
     }
   } else if (f.F == 32) hipLaunchKernelGGL((fcomb_bwd_kernel<T, 32>), grid, dim3(256), lds, s, a, zb, dzb);
   else if (f.F == 16) hipLaunchKernelGGL((fcomb_bwd_kernel<T, 16>), grid, dim3(256), lds, s, a, zb, dzb);
