@@ -267,6 +267,8 @@ class ProbabilisticUNet(nn.Module):
         self.recon = recon
         self.dropout = float(dropout)
         self.sync_scalars = True          # reference returns python floats (.item()); set False to keep device scalars
+        self.assume_static_parameters = False   # True: forward calls do not re-pack the weights (inference loops; see _params_dirty)
+        self._packed_once = False
         self._pls = None                  # prior_latent_space / posterior_latent_space: a distribution, None, or a pending
         self._qls = None                  # fetch (int B) filled from the engine on first access after a fused elbo()
         self._want_batch, self._want_members = int(max_batch), int(max_members)
@@ -395,6 +397,7 @@ class ProbabilisticUNet(nn.Module):
         ctx = C.c_void_p()
         L.check(L.lib().pu_create(C.byref(cfg), dev.index or 0, C.byref(ctx)), None, "pu_create")
         self._ctx, self._ctx_key = ctx, key
+        self._packed_once = False
         n = L.lib().pu_param_count(ctx)
         if n != self._nparams:
             raise L.ProbUNetLibraryError(f"parameter count mismatch: engine {n} vs host {self._nparams}")
@@ -447,8 +450,14 @@ class ProbabilisticUNet(nn.Module):
             self._anchor = torch.zeros(1, device=self._owner_device(), requires_grad=True)
         return self._anchor
 
-    def _params_dirty(self):
-        L.lib().pu_params_changed(self._ctx)
+    def _params_dirty(self, force: bool = True):
+        """Tell the engine that the fp32 parameters may have changed (it re-packs its compute-dtype copies, 0.4 ms at cfg3).
+        The forward entry points call this with force=False: skipped when `assume_static_parameters` is set (an explicit opt-in
+        for sampling loops - torch cannot tell us about writes through `.data` - that optimizers, load_state_dict and
+        enable_data_parallel override by forcing)."""
+        if force or not self.assume_static_parameters or not self._packed_once:
+            L.lib().pu_params_changed(self._ctx)
+            self._packed_once = True
 
     def _deliver(self, g, lo, hi):
         """Engine gradients [lo, hi) (x grad_output g) -> p.grad (accumulating like autograd does).
@@ -537,7 +546,7 @@ class ProbabilisticUNet(nn.Module):
         if Cc != self.input_channels:
             raise ValueError(f"expected {self.input_channels} input planes, got {Cc}")
         self._ensure(H, W, B, 1)
-        self._params_dirty()
+        self._params_dirty(force=False)
         feat = torch.empty(B, self.num_filters[0], H, W, device=x.device, dtype=torch.float32)
         train = 1 if (self.training and self.dropout > 0) else 0
         L.check(L.lib().pu_unet_fwd(self._ctx, L.ptr(x), L.ptr(feat), B, train, self._next_seed(), L.current_stream()), self._ctx, "pu_unet_fwd")
@@ -547,7 +556,7 @@ class ProbabilisticUNet(nn.Module):
         x = self._prep(x)
         B, Cc, H, W = x.shape
         self._ensure(H, W, B, 1)
-        self._params_dirty()
+        self._params_dirty(force=False)
         if which == L.PU_POSTERIOR:
             target = self._prep(target)
             if target.shape[1] != self.num_classes:
@@ -574,7 +583,7 @@ class ProbabilisticUNet(nn.Module):
             src = feat.contiguous(); bstride = F0 * H * W
         src = src.float()
         self._ensure(H, W, B, 1)
-        self._params_dirty()
+        self._params_dirty(force=False)
         out = torch.empty(B, self.num_classes, H, W, device=feat.device, dtype=torch.float32)
         L.check(L.lib().pu_fcomb_fwd(self._ctx, L.ptr(src), bstride, L.ptr(z.contiguous().float()), L.ptr(out), B, L.current_stream()),
                 self._ctx, "pu_fcomb_fwd")
@@ -640,7 +649,7 @@ class ProbabilisticUNet(nn.Module):
             raise AssertionError("Image size should be larger than 96 due to the 4 downsamplings in ms-ssim")
         Mx = M if (afcrps or msssim) else 1
         self._ensure(H, W, B, Mx)
-        self._params_dirty()
+        self._params_dirty(force=False)
         if eps is None:
             eps = torch.randn(Mx, B, self.latent_dim, device=x.device, dtype=torch.float32)
         eps = eps.contiguous().float()
@@ -687,7 +696,7 @@ class ProbabilisticUNet(nn.Module):
         x = self._prep(x)
         B, Cc, H, W = x.shape
         self._ensure(H, W, B, n)
-        self._params_dirty()
+        self._params_dirty(force=False)
         if target is not None:
             target = self._prep(target)
             if target.shape[1] != self.num_classes:
@@ -713,7 +722,7 @@ class ProbabilisticUNet(nn.Module):
         x = self._prep(x)
         B, Cc, H, W = x.shape
         self._ensure(H, W, B, n)
-        self._params_dirty()
+        self._params_dirty(force=False)
         if target is not None:
             target = self._prep(target)
             if target.shape[1] != self.num_classes:

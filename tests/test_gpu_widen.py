@@ -283,3 +283,23 @@ def test_ensemble_size_15_as_in_main_py(M):
     assert max(rels) < 2e-2 and float(np.median(rels)) < 2e-3, (max(rels), float(np.median(rels)))
     with pytest.raises(pa._lib.ProbUNetLibraryError):
         m.elbo(x.to(DEV), y.to(DEV), None, M=33)
+
+
+def test_assume_static_parameters_opt_in():
+    """Inference loops may skip the per-call weight re-pack; optimizers / load_state_dict still force it."""
+    m, cfg, P = _small_model("afcrps", dtype="f16", H=32)
+    m.eval()
+    x, _ = make_fields(2, 2, 1, 32, 32, seed=15); x = x.to(DEV); eps = make_eps(2, 2, 4).to(DEV)
+    a = m.sample(x, 2, eps=eps).clone()
+    m.assume_static_parameters = True
+    b = m.sample(x, 2, eps=eps).clone()
+    assert torch.equal(a, b)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    sd["fcomb.layers.4.bias"] = sd["fcomb.layers.4.bias"] + 1.0
+    m.load_state_dict(sd)                                        # forces the re-pack (fcomb reads fp32 params directly; unet weights too)
+    sd["unet.out_conv.weight"] = sd["unet.out_conv.weight"] * 0.5
+    m.load_state_dict(sd)
+    c = m.sample(x, 2, eps=eps)
+    assert not torch.allclose(c, b + 1.0, atol=1e-3)             # the halved out_conv weights were re-packed and changed the features
+    m2, _, _ = _small_model("afcrps", dtype="f16", H=32); m2.eval(); m2.load_state_dict(sd)
+    assert torch.equal(m2.sample(x, 2, eps=eps), c)
