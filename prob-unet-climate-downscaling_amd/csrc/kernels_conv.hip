@@ -1059,6 +1059,7 @@ template hipError_t launch_wgrad<bf16>(const WgradArgs&, hipStream_t);
 template <typename T>
 __global__ void pack_weights_kernel(const float* __restrict__ params, T* __restrict__ packed, const PackDesc* __restrict__ descs) {
   const PackDesc d = descs[blockIdx.y];
+  if (sizeof(T) == 2 && d.mode >= 2) return;               // fragment-major descriptors: pack_frag_kernel
   const long total = (long)d.rows_pk * d.taps * d.k_pk;
   const float* w = params + d.src_off;
   T* dst = packed + d.dst_off;
@@ -1086,10 +1087,60 @@ __global__ void pack_weights_kernel(const float* __restrict__ params, T* __restr
   }
 }
 
+// Fragment-major descriptors (modes 2 / 3) through LDS: a block takes one (row tile, 32-channel chunk) = 32 x 32 x taps weights.
+// Their fp32 sources are 32 contiguous runs of 32 * taps floats (forward: one run per cout over its cin range; data gradient:
+// one run per cout over the cin ROW range), read coalesced into LDS rows of 32 * taps + 1 floats (conflict-free re-read), then
+// written as 16-byte fragment vectors.  The element-wise kernel above gathers with a 36-byte stride and runs at a third of this.
+template <typename T>
+__global__ __launch_bounds__(256) void pack_frag_kernel(const float* __restrict__ params, T* __restrict__ packed, const PackDesc* __restrict__ descs) {
+  static_assert(sizeof(T) == 2, "fragment layouts exist for the 16-bit engines only");
+  __shared__ float sm[32][32 * 9 + 1];
+  const PackDesc d = descs[blockIdx.y];
+  if (d.mode < 2) return;
+  const bool dgrad = d.mode == 3;
+  const int taps = d.taps, run = 32 * taps, nch = d.k_pk / 32, nct = d.rows_pk / 32;
+  const float* w = params + d.src_off;
+  const int tid = threadIdx.x;
+  for (int tile = blockIdx.x; tile < nct * nch; tile += gridDim.x) {
+    const int ct = tile / nch, c = tile - ct * nch;
+    __syncthreads();                                       // previous tile's reads are done
+    // run q (0..31) = cout index within the tile's cout range; elements = (cin offset within the tile's cin range) * taps + tap
+    constexpr int U = 9;                                   // nine loads in flight per thread before the first LDS store
+    for (int j0 = 0; j0 < 32 * run; j0 += 256 * U) {
+      float tmp[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = j0 + u * 256 + tid;
+        const int q = i / run, o = i - q * run;
+        const int co = (dgrad ? c : ct) * 32 + q, ci = (dgrad ? ct : c) * 32 + o / taps;
+        tmp[u] = (i < 32 * run && co < d.Cout && ci < d.Cin) ? w[((size_t)co * d.Cin + (dgrad ? ct : c) * 32) * taps + o] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int i = j0 + u * 256 + tid;
+        if (i < 32 * run) { const int q = i / run; sm[q][i - q * run] = tmp[u]; }
+      }
+    }
+    __syncthreads();
+    T* dst = packed + d.dst_off + (size_t)tile * taps * 2 * 512;
+    for (int v = tid; v < taps * 2 * 64; v += 256) {       // one 8-element fragment vector per iteration
+      const int lane = v & 63, kk = (v >> 6) & 1, t = v >> 7;
+      const int r = lane & 31, k0 = kk * 16 + 8 * (lane >> 5);
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = dgrad ? sm[k0 + e][r * taps + (taps - 1 - t)] : sm[r][(k0 + e) * taps + t];
+      *reinterpret_cast<V16*>(dst + (size_t)v * 8) = pack<T>(o);
+    }
+  }
+}
+
 template <typename T>
 hipError_t launch_pack(const float* params, void* packed, const PackDesc* descs_dev, int ndesc, hipStream_t s) {
   if (ndesc == 0) return hipSuccess;
+  // row-major descriptors (and every fp32 one) element-wise; fragment-major ones through LDS (each kernel skips the other kind)
   hipLaunchKernelGGL(pack_weights_kernel<T>, dim3(288, ndesc), dim3(256), 0, s, params, reinterpret_cast<T*>(packed), descs_dev);
+  if constexpr (sizeof(T) == 2)
+    hipLaunchKernelGGL(pack_frag_kernel<T>, dim3(64, ndesc), dim3(256), 0, s, params, reinterpret_cast<T*>(packed), descs_dev);
   return hipGetLastError();
 }
 template hipError_t launch_pack<float>(const float*, void*, const PackDesc*, int, hipStream_t);
