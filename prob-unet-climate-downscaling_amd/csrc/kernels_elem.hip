@@ -616,6 +616,126 @@ __global__ __launch_bounds__(256) void gn_bwd_pass2_kernel(GNBwdArgs a) {
   }
 }
 
+// ---- small tensors (H*W <= 1024, the 32^2 / 16^2 levels): the whole backward of one (sample, bundle of whole groups) in ONE block:
+// pass 1, the group reduction, the per-channel coefficients, the parameter gradients and pass 2 without leaving the kernel.  At
+// these sizes the three-kernel form is launch-bound (8-10 us kernels with 2 us gaps); the second read of x / dy hits L2.
+static inline int gn_bundle_channels(int C, int G) {      // channels per block: a multiple of the group size and of 8, >= 32 if possible
+  const int cpg = C / G;
+  int cb = cpg;
+  while (cb % 8) cb += cpg;
+  if (cb > 64 || C % cb) return 0;
+  while (cb < 32 && C % (2 * cb) == 0) cb *= 2;
+  return cb;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void gn_small_bwd_kernel(GNBwdArgs a, int CB) {
+  constexpr int VEC = 8;
+  static_assert(ET<T>::VEC == 8, "16-bit engines");
+  __shared__ float red[256 * 16];                          // [thread][8 channels][S1, S2]
+  __shared__ float chs[64 * 2];                            // per channel of the bundle: S1, S2 over the sample
+  __shared__ float cof[64 * 3];                            // per channel: dx = o0 dv + o1 (x - mean) + o2
+  const GNArgs& f = a.f;
+  const int C = f.x.C, G = f.G, cpg = C / G, b = blockIdx.y, c0 = blockIdx.x * CB;
+  const int CVb = CB / VEC, PL = 256 / CVb, tid = threadIdx.x, cv = tid % CVb, pl = tid / CVb;
+  const bool act = pl < PL;
+  const long HW = (long)f.x.H * f.x.W;
+  const T* xp = reinterpret_cast<const T*>(f.x.p) + (long)b * HW * f.x.ld + c0 + cv * VEC;
+  const T* dyp = reinterpret_cast<const T*>(a.dy.p) + (long)b * HW * a.dy.ld + c0 + cv * VEC;
+  T* dxp = reinterpret_cast<T*>(a.dx.p) + (long)b * HW * a.dx.ld + c0 + cv * VEC;
+  const T* addp = a.add.p ? reinterpret_cast<const T*>(a.add.p) + (long)b * HW * a.add.ld + c0 + cv * VEC : nullptr;
+  const float keep = 1.f - f.drop_p, inv_keep = f.drop_p > 0.f ? 1.f / keep : 1.f;
+  const uint32_t dkey = drop_key(f.drop_seed, f.drop_stream), dthr = drop_thr16(keep);
+  float A[VEC], Bc[VEC], mu[VEC], rs[VEC], s1[VEC], s2[VEC];
+  {
+    const float4* q1 = reinterpret_cast<const float4*>(f.coef) + ((long)b * C + c0 + cv * VEC);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { const float4 q4 = q1[e]; A[e] = q4.x; Bc[e] = q4.y; mu[e] = q4.z; rs[e] = q4.w; s1[e] = 0.f; s2[e] = 0.f; }
+  }
+  auto dv_of = [&](long p, const V16& rx, const V16& rd, float* xv, float* dv) {
+    float dh[VEC];
+    unpack<T>(rx, xv); unpack<T>(rd, dh);
+    if (f.drop_p > 0.f) {
+      const uint64_t base = ((uint64_t)(b + f.b0) * HW + p) * (uint64_t)C + (uint64_t)(c0 + cv * VEC);
+#pragma unroll
+      for (int e = 0; e < VEC; e += 2) {
+        const uint32_t r = drop_pair(dkey, base + e);
+        dh[e] = (r & 0xffffu) < dthr ? dh[e] * inv_keep : 0.f;
+        dh[e + 1] = (r >> 16) < dthr ? dh[e + 1] * inv_keep : 0.f;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) dv[e] = dh[e] * dsilu_f<false>(A[e] * (xv[e] - mu[e]) + Bc[e]);
+  };
+  if (act) {
+    for (long p = pl; p < HW; p += 2 * PL) {                  // two pixels per trip, loads first
+      const long p2 = p + PL;
+      const bool ok2 = p2 < HW;
+      const V16 rx0 = ldv<T>(xp + p * f.x.ld), rd0 = ldv<T>(dyp + p * a.dy.ld);
+      const V16 rx1 = ldv<T>(xp + (ok2 ? p2 : p) * f.x.ld), rd1 = ldv<T>(dyp + (ok2 ? p2 : p) * a.dy.ld);
+      float xv[VEC], dv[VEC];
+      dv_of(p, rx0, rd0, xv, dv);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) { s1[e] += dv[e]; s2[e] += dv[e] * (xv[e] - mu[e]) * rs[e]; }
+      if (ok2) {
+        dv_of(p2, rx1, rd1, xv, dv);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { s1[e] += dv[e]; s2[e] += dv[e] * (xv[e] - mu[e]) * rs[e]; }
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) { red[tid * 16 + e * 2] = act ? s1[e] : 0.f; red[tid * 16 + e * 2 + 1] = act ? s2[e] : 0.f; }
+  __syncthreads();
+  if (tid < CB * 2) {                                        // (channel, which) totals over the pixel lanes, fixed order
+    const int ch = tid >> 1, which = tid & 1, cvv = ch / VEC, e = ch % VEC;
+    float t = 0.f;
+    for (int q = 0; q < PL; ++q) t += red[(q * CVb + cvv) * 16 + e * 2 + which];
+    chs[tid] = t;
+  }
+  __syncthreads();
+  if (tid < CB) {
+    const int c = c0 + tid, gl = tid / cpg;
+    float m1 = 0.f, m2 = 0.f;
+    for (int cc = gl * cpg; cc < (gl + 1) * cpg; ++cc) {
+      const float gp = f.gamma[c0 + cc] * (1.f + (f.scale ? f.scale[c0 + cc] : 0.f));
+      m1 += gp * chs[cc * 2]; m2 += gp * chs[cc * 2 + 1];
+    }
+    const float n = (float)cpg * (float)HW;
+    m1 /= n; m2 /= n;
+    const float rstd = reinterpret_cast<const float4*>(f.coef)[(long)b * C + c].w;
+    const float sc = f.scale ? f.scale[c] : 0.f, gp = f.gamma[c] * (1.f + sc);
+    cof[tid * 3] = rstd * gp; cof[tid * 3 + 1] = -rstd * rstd * m2; cof[tid * 3 + 2] = -rstd * m1;
+    const float S1 = chs[tid * 2] * a.inv_scale, S2 = chs[tid * 2 + 1] * a.inv_scale;
+    atomicAdd(a.dgamma + c, (1.f + sc) * S2);
+    atomicAdd(a.dbeta + c, (1.f + sc) * S1);
+    if (a.dscale) atomicAdd(a.dscale + c, f.gamma[c] * S2 + f.beta[c] * S1);
+    if (a.dshift) atomicAdd(a.dshift + c, S1);
+  }
+  __syncthreads();
+  if (!act) return;
+  float o0[VEC], o1[VEC], o2[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) { o0[e] = cof[(cv * VEC + e) * 3]; o1[e] = cof[(cv * VEC + e) * 3 + 1]; o2[e] = cof[(cv * VEC + e) * 3 + 2]; }
+  for (long p = pl; p < HW; p += PL) {
+    const V16 rx = ldv<T>(xp + p * f.x.ld), rd = ldv<T>(dyp + p * a.dy.ld);
+    float xv[VEC], dv[VEC], o[VEC];
+    if (a.accumulate) unpack<T>(ldv<T>(dxp + p * a.dx.ld), o);
+    else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) o[e] = 0.f;
+    }
+    if (addp) {
+      float av[VEC]; unpack<T>(ldv<T>(addp + p * a.add.ld), av);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) o[e] += av[e];
+    }
+    dv_of(p, rx, rd, xv, dv);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) o[e] += o0[e] * dv[e] + o1[e] * (xv[e] - mu[e]) + o2[e];
+    stv<T>(dxp + p * a.dx.ld, pack<T>(o));
+  }
+}
+
 template <typename T>
 hipError_t launch_gn_bwd(const GNBwdArgs& a0, hipStream_t s) {
   const int step = gn_batch_chunk(a0.f.x, sizeof(T));
@@ -627,6 +747,14 @@ hipError_t launch_gn_bwd(const GNBwdArgs& a0, hipStream_t s) {
     a.add = tv_batch(a0.add, b0, nb, sizeof(T));
     a.part2 = a0.part2 + (size_t)b0 * a0.f.nchunk * a0.f.x.C * 2; a.coef2 = a0.coef2 + (size_t)b0 * a0.f.x.C * 3;
     const GNArgs& f = a.f;
+    if constexpr (sizeof(T) == 2) {
+      static const bool no_small = getenv("PU_NO_GN_SMALL") != nullptr;
+      const int cb = gn_bundle_channels(f.x.C, f.G);
+      if (!no_small && f.resample == RS_NONE && (long)f.x.H * f.x.W <= 1024 && cb > 0) {
+        hipLaunchKernelGGL(gn_small_bwd_kernel<T>, dim3(f.x.C / cb, f.x.B), dim3(256), 0, s, a, cb);
+        continue;
+      }
+    }
     dim3 g1(f.nchunk, f.x.B);
     if (f.resample == RS_NONE) hipLaunchKernelGGL((gn_bwd_pass1_kernel<T, RS_NONE>), g1, dim3(256), 0, s, a);
     else if (f.resample == RS_DOWN) hipLaunchKernelGGL((gn_bwd_pass1_kernel<T, RS_DOWN>), g1, dim3(256), 0, s, a);
