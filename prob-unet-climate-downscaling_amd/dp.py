@@ -31,10 +31,10 @@ def init_from_env(backend: Optional[str] = None):
     return rank, local_rank, world
 
 
-def allreduce_mean_(flat: torch.Tensor, group=None, bucket_elems: int = 0) -> torch.Tensor:
+def allreduce_mean_(flat: torch.Tensor, group=None, bucket_elems: int = 0, average: bool = True) -> torch.Tensor:
     """In-place mean over the process group of a flat gradient buffer.  bucket_elems > 0 splits the reduction into
     buckets of that many elements (point-to-point xGMI rings are per-link bound, so a few large buckets are best);
-    0 = one collective."""
+    0 = one collective.  average=False leaves the SUM in place (the caller folds 1 / world into a pass it makes anyway)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         return flat
@@ -45,7 +45,8 @@ def allreduce_mean_(flat: torch.Tensor, group=None, bucket_elems: int = 0) -> to
                  for i in range(0, flat.numel(), bucket_elems)]
         for w in works:
             w.wait()
-    flat.mul_(1.0 / world)
+    if average:
+        flat.mul_(1.0 / world)
     return flat
 
 
