@@ -188,11 +188,18 @@ def main():
             raise SystemExit("--gpus N>1 must be launched with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
                              "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
     import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # PU_BENCH_REHEARSAL=1: every rank on GPU 0 with the gloo backend - exercises the multi-rank control flow of this script on a
+    # one-GPU box (RCCL refuses two ranks on one device).  Never used for reported numbers.
+    rehearsal = os.environ.get("PU_BENCH_REHEARSAL") == "1"
+    dev_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     cfg = dict(CFG3, batch=args.batch, M=args.members)
     model = build_model(cfg, args.dtype, device, args.recon)
