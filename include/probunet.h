@@ -71,7 +71,7 @@ typedef struct {
 } pu_param_desc;
 
 /* Scalars written by pu_elbo_fwd_bwd (device array of PU_NUM_SCALARS floats). */
-enum { PU_S_TOTAL = 0, PU_S_RECON = 1, PU_S_KL_MEAN = 2, PU_S_KL2_MEAN = 3, PU_S_WMSE = 4, PU_S_MSSSIM = 5, PU_NUM_SCALARS = 8 };
+enum { PU_S_TOTAL = 0, PU_S_RECON = 1, PU_S_KL_MEAN = 2, PU_S_KL2_MEAN = 3, PU_S_WMSE = 4, PU_S_MSSSIM = 5, PU_S_NONFINITE = 6, PU_NUM_SCALARS = 8 };
 
 /* ---- lifetime (replaces ProbabilisticUNet.__init__, prob_unet.py:146-189) ------------------------------- */
 int pu_create(const pu_config* cfg, int device, pu_ctx** out);
@@ -155,6 +155,11 @@ int pu_lrinterp_to_residuals(const float* hr, int B, int C, int H, int W, int k,
  *      the flat buffers: one fused pass; exp_avg / exp_avg_sq are caller-owned fp32 arrays of n elements; step counts from 1. */
 int pu_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int64_t step, void* stream);
+/* Same; when skip_flag (device float, nullable) is non-zero the kernel leaves parameters and moments untouched.  The f16 engine
+ * sets out_scalars[PU_S_NONFINITE] = 1 in pu_elbo_fwd_bwd when a parameter gradient came out inf / NaN (fp16 overflow): passing
+ * that address skips the poisoned step on the device, the way torch.cuda.amp.GradScaler does with a host sync. */
+int pu_adamw_step_guarded(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                          float beta2, float eps, float weight_decay, int64_t step, const float* skip_flag, void* stream);
 
 /* ---- introspection for bench/roofline ------------------------------------------------------------------ */
 int64_t pu_workspace_bytes(pu_ctx*);

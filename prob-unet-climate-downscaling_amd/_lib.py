@@ -9,7 +9,7 @@ PU_MAX_LEVELS = 8
 PU_F32, PU_F16, PU_BF16 = 0, 1, 2
 PU_PRIOR, PU_POSTERIOR = 0, 1
 PU_RECON_AFCRPS, PU_RECON_L1, PU_RECON_WMSE_MSSSIM = 0, 1, 2
-PU_S_TOTAL, PU_S_RECON, PU_S_KL_MEAN, PU_S_KL2_MEAN, PU_S_WMSE, PU_S_MSSSIM, PU_NUM_SCALARS = 0, 1, 2, 3, 4, 5, 8
+PU_S_TOTAL, PU_S_RECON, PU_S_KL_MEAN, PU_S_KL2_MEAN, PU_S_WMSE, PU_S_MSSSIM, PU_S_NONFINITE, PU_NUM_SCALARS = 0, 1, 2, 3, 4, 5, 6, 8
 DTYPES = {"f32": PU_F32, "fp32": PU_F32, "float32": PU_F32, "f16": PU_F16, "fp16": PU_F16, "float16": PU_F16,
           "bf16": PU_BF16, "bfloat16": PU_BF16}
 
@@ -82,6 +82,8 @@ def lib():
     L.pu_profile_enable.restype = i32; L.pu_profile_enable.argtypes = [i32]
     L.pu_adamw_step.restype = i32
     L.pu_adamw_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i64, vp]
+    L.pu_adamw_step_guarded.restype = i32
+    L.pu_adamw_step_guarded.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i64, vp, vp]
     L.pu_set_overlap.restype = i32; L.pu_set_overlap.argtypes = [vp, i32]
     L.pu_profile_collect.restype = i32; L.pu_profile_collect.argtypes = [C.POINTER(PuProfEntry), i32]
     L.pu_op_conv.restype = i32

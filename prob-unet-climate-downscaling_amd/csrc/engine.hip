@@ -753,13 +753,17 @@ int pu_param_table(pu_ctx* c, const pu_param_desc** out, int* n) {
 }
 int64_t pu_param_count(pu_ctx* c) { return c ? c->nparams : -1; }
 int pu_profile_enable(int on) { prof_enable(on != 0); return PU_OK; }
-int pu_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
-                  float eps, float weight_decay, int64_t step, void* stream) {
+int pu_adamw_step_guarded(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
+                          float eps, float weight_decay, int64_t step, const float* skip_flag, void* stream) {
   if (!params || !grads || !exp_avg || !exp_avg_sq || n < 0 || step < 1) return PU_ERR_INVALID;
   const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
   const hipError_t e = launch_adamw_flat(params, grads, exp_avg, exp_avg_sq, (long)n, lr, beta1, beta2, eps, weight_decay,
-                                         (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), (hipStream_t)stream);
+                                         (float)((double)lr / bc1), (float)(1.0 / sqrt(bc2)), (hipStream_t)stream, skip_flag);
   return e == hipSuccess ? PU_OK : PU_ERR_HIP;
+}
+int pu_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, int64_t step, void* stream) {
+  return pu_adamw_step_guarded(params, grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, weight_decay, step, nullptr, stream);
 }
 int pu_set_overlap(pu_ctx* c, int on) {
   if (!c) return PU_ERR_INVALID;
@@ -995,7 +999,14 @@ int pu_elbo_fwd_bwd(pu_ctx* c, const float* x, const float* target, const float*
           return gauss_backward<T>(c, c->prior, s2);
         }))) return q;
     if ((q = join2(c, s, s2))) return q;
-    return join_side(c, s);
+    if ((q = join_side(c, s))) return q;
+    if (c->dt == PU_F16) {
+      // fp16 activations can overflow (diverging training, a loss scale set too high): flag non-finite parameter gradients so
+      // that the optimizer step can be skipped on the device (pu_adamw_step_guarded); one read of the flat buffer, ~60 us
+      CKH(launch_nonfinite_flag(c->grads, (long)c->nparams, c->scal + PU_S_NONFINITE, s));
+      if (out_scalars) CKH(hipMemcpyAsync(out_scalars + PU_S_NONFINITE, c->scal + PU_S_NONFINITE, sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    return PU_OK;
   });
 }
 

@@ -1232,7 +1232,9 @@ hipError_t launch_fill(float* p, float v, long n, hipStream_t s) {
 // ------------------------------------------------------------------ flat AdamW (torch.optim.AdamW semantics, main.py:103)
 // One pass over the flat fp32 buffers (parameters, gradients, exp_avg, exp_avg_sq): 4 reads + 3 writes per element.
 __global__ void adamw_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
-                                  float lr, float beta1, float beta2, float eps, float wd, float step_size, float inv_bc2_sqrt) {
+                                  float lr, float beta1, float beta2, float eps, float wd, float step_size, float inv_bc2_sqrt,
+                                  const float* __restrict__ skip_flag) {
+  if (skip_flag && skip_flag[0] != 0.f) return;          // the gradients of this step were flagged non-finite: leave everything untouched
   for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long)gridDim.x * blockDim.x * 4) {
     if (i + 4 <= n) {
       f32x4 pp = *reinterpret_cast<f32x4*>(p + i), gg = *reinterpret_cast<const f32x4*>(g + i);
@@ -1257,8 +1259,26 @@ __global__ void adamw_flat_kernel(float* __restrict__ p, const float* __restrict
   }
 }
 hipError_t launch_adamw_flat(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps, float wd,
-                             float step_size, float inv_bc2_sqrt, hipStream_t s) {
-  hipLaunchKernelGGL(adamw_flat_kernel, dim3(ew_grid((n + 3) / 4)), dim3(256), 0, s, p, g, m, v, n, lr, beta1, beta2, eps, wd, step_size, inv_bc2_sqrt);
+                             float step_size, float inv_bc2_sqrt, hipStream_t s, const float* skip_flag) {
+  hipLaunchKernelGGL(adamw_flat_kernel, dim3(ew_grid((n + 3) / 4)), dim3(256), 0, s, p, g, m, v, n, lr, beta1, beta2, eps, wd, step_size, inv_bc2_sqrt,
+                     skip_flag);
+  return hipGetLastError();
+}
+// flag[0] = 1 if any of the n floats is inf / NaN (the flag must have been zeroed before)
+__global__ __launch_bounds__(256) void nonfinite_flag_kernel(const float* __restrict__ g, long n, float* __restrict__ flag) {
+  bool bad = false;
+  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long)gridDim.x * blockDim.x * 4) {
+    if (i + 4 <= n) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(g + i);
+      bad |= !(isfinite(v[0]) && isfinite(v[1]) && isfinite(v[2]) && isfinite(v[3]));
+    } else {
+      for (long k = i; k < n; ++k) bad |= !isfinite(g[k]);
+    }
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) flag[0] = 1.f;
+}
+hipError_t launch_nonfinite_flag(const float* g, long n, float* flag, hipStream_t s) {
+  hipLaunchKernelGGL(nonfinite_flag_kernel, dim3(ew_grid((n + 3) / 4)), dim3(256), 0, s, g, n, flag);
   return hipGetLastError();
 }
 

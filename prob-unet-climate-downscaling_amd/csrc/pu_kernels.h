@@ -158,7 +158,8 @@ template <typename T> hipError_t launch_fcomb_bwd(const FcombBwdArgs&, hipStream
 
 hipError_t launch_fill(float* p, float v, long n, hipStream_t);
 hipError_t launch_adamw_flat(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps, float wd,
-                             float step_size, float inv_bc2_sqrt, hipStream_t);
+                             float step_size, float inv_bc2_sqrt, hipStream_t, const float* skip_flag = nullptr);
+hipError_t launch_nonfinite_flag(const float* g, long n, float* flag, hipStream_t);
 
 // ---------------------------------------------------------------- optional per-kernel-class profiling (bench roofline)
 // When enabled, every MFMA conv launch is bracketed by HIP events on its own stream; prof_collect() sums elapsed time,

@@ -248,7 +248,7 @@ class ProbabilisticUNet(nn.Module):
 
     def __init__(self, input_channels, num_classes, latent_dim, num_filters, model_channels, channel_mult,
                  beta_0, beta_1, beta_2, *, dtype: str = "f32", max_batch: int = 0, max_members: int = 0,
-                 recon: str = "afcrps", dropout: float = 0.10, init: bool = True):
+                 recon: str = "afcrps", dropout: float = 0.10, init: bool = True, grad_scale: float = 0.0):
         super().__init__()
         self.input_channels = int(input_channels)
         self.num_classes = int(num_classes)
@@ -266,6 +266,7 @@ class ProbabilisticUNet(nn.Module):
             raise ValueError('recon must be "afcrps", "l1" or "wmse_msssim"')
         self.recon = recon
         self.dropout = float(dropout)
+        self.grad_scale = float(grad_scale)   # f16 static loss scale (0 = sized automatically from B, M, C, H, W)
         self.sync_scalars = True          # reference returns python floats (.item()); set False to keep device scalars
         self.assume_static_parameters = False   # True: forward calls do not re-pack the weights (inference loops; see _params_dirty)
         self._packed_once = False
@@ -388,7 +389,7 @@ class ProbabilisticUNet(nn.Module):
                                          "this engine has no CPU path")
         mb = max(B, self._want_batch, self._ctx_key[2] if self._ctx_key else 0)
         mm = max(M, self._want_members, self._ctx_key[3] if self._ctx_key else 0, 1)
-        key = (H, W, mb, mm, self.compute_dtype, dev.index or 0, self.dropout)
+        key = (H, W, mb, mm, self.compute_dtype, dev.index or 0, self.dropout, float(getattr(self, "grad_scale", 0.0)))
         if self._ctx is not None and self._ctx_key == key:
             self._check_views()
             return
@@ -845,6 +846,7 @@ class FlatAdamW:
     def __init__(self, model: ProbabilisticUNet, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
         self.model, self.lr, self.betas, self.eps, self.weight_decay = model, lr, betas, eps, weight_decay
         self.step_count = 0
+        self.skip_nonfinite = True        # f16 engine only: leave parameters untouched when the gradients overflowed (see step())
         self.exp_avg = None
         self.exp_avg_sq = None
 
@@ -867,7 +869,13 @@ class FlatAdamW:
             for p, off, n in m._params_in(0, m._nparams):
                 m._flat_grad[off:off + n].copy_((p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1))
         self.step_count += 1
-        L.check(L.lib().pu_adamw_step(L.ptr(m._flat), L.ptr(m._flat_grad), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq), m._nparams,
-                                      float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
-                                      float(self.weight_decay), self.step_count, L.current_stream()), m._ctx, "pu_adamw_step")
+        # f16 engine: the step is skipped ON THE DEVICE when the engine flagged non-finite gradients for the last elbo() (no host sync)
+        flag = None
+        sc = getattr(m, "_last_scalars", None)
+        if self.skip_nonfinite and m.compute_dtype in ("f16", "fp16", "float16") and sc is not None and sc.device == m._flat.device:
+            flag = C.c_void_p(sc.data_ptr() + 4 * L.PU_S_NONFINITE)
+            self._flag_owner = sc                                  # keep the scalars alive until the kernel has run
+        L.check(L.lib().pu_adamw_step_guarded(L.ptr(m._flat), L.ptr(m._flat_grad), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq), m._nparams,
+                                              float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
+                                              float(self.weight_decay), self.step_count, flag, L.current_stream()), m._ctx, "pu_adamw_step")
         m._params_dirty()

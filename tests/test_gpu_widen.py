@@ -303,3 +303,24 @@ def test_assume_static_parameters_opt_in():
     assert not torch.allclose(c, b + 1.0, atol=1e-3)             # the halved out_conv weights were re-packed and changed the features
     m2, _, _ = _small_model("afcrps", dtype="f16", H=32); m2.eval(); m2.load_state_dict(sd)
     assert torch.equal(m2.sample(x, 2, eps=eps), c)
+
+
+def test_f16_overflow_is_flagged_and_the_step_skipped_on_device():
+    """A loss scale far too high overflows the fp16 activation gradients: the engine flags non-finite parameter gradients
+    (PU_S_NONFINITE) and the flat AdamW leaves parameters and moments untouched, without a host sync; with the automatic scale
+    the flag stays 0 and the step is taken."""
+    x, y = make_fields(2, 2, 1, 32, 32, seed=16); eps = make_eps(2, 2, 4)
+    for scale, expect in ((2.0 ** 40, 1.0), (0.0, 0.0)):
+        m, cfg, P = _small_model("afcrps", dtype="f16", H=32)
+        m.grad_scale = scale
+        m.train(); m.dropout = 0.0
+        opt = pa.FlatAdamW(m, lr=1e-2)
+        before = torch.cat([p.detach().flatten() for p in m.parameters()]).clone()
+        loss, _, _ = m.elbo(x.to(DEV), y.to(DEV), None, M=2, eps=eps.to(DEV))
+        opt.zero_grad(); loss.backward(); opt.step()
+        after = torch.cat([p.detach().flatten() for p in m.parameters()])
+        assert float(m._last_scalars[L.PU_S_NONFINITE]) == expect
+        if expect:
+            assert torch.equal(before, after) and float(opt.exp_avg.abs().sum()) == 0.0
+        else:
+            assert not torch.equal(before, after) and torch.isfinite(after).all()
