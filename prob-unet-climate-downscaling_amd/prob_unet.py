@@ -472,6 +472,11 @@ class ProbabilisticUNet(nn.Module):
             from .dp import allreduce_mean_
             # the 1 / world of the mean rides on the copy below when there is one (saves a pass over the 300 MB buffer)
             allreduce_mean_(eg, self._dp_group, self.dp_bucket_elems, average=not fresh)
+            sc = getattr(self, "_last_scalars", None)
+            if self.compute_dtype in ("f16", "fp16", "float16") and sc is not None and lo == 0 and hi == self._nparams:
+                # an overflow on ANY rank poisons the averaged gradient of EVERY rank: share the flag so that all ranks skip together
+                import torch.distributed as dist
+                dist.all_reduce(sc[L.PU_S_NONFINITE:L.PU_S_NONFINITE + 1], op=dist.ReduceOp.MAX, group=self._dp_group)
             if fresh:
                 g = (g.reshape(()) if g is not None else torch.ones((), device=eg.device)) * (1.0 / self._dp_world)
         if fresh:

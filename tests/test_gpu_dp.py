@@ -52,6 +52,41 @@ def _worker(rank, world, initfile, outdir):
     dist.destroy_process_group()
 
 
+def _worker_overflow(rank, world, initfile, outdir):
+    sys.path.insert(0, ROOT)
+    import probunet_amd as pa
+    from probunet_amd import _lib as L
+    from tests.filler import make_fields, make_eps
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method=f"file://{initfile}", rank=rank, world_size=world)
+    torch.manual_seed(7)
+    m = pa.ProbabilisticUNet(2, 1, 4, [8, 16], 8, [1, 2], 0.7, 1.3, 0.0, dtype="f16", grad_scale=(2.0 ** 40 if rank == 1 else 0.0)).to(dev).train()
+    m.dropout = 0.0
+    m.enable_data_parallel()
+    x, y = make_fields(4, 2, 1, 32, 32, seed=41); eps = make_eps(2, 4, 4)
+    xs, ys = pa.dp.shard_batch(x, rank, world).contiguous().to(dev), pa.dp.shard_batch(y, rank, world).contiguous().to(dev)
+    opt = pa.FlatAdamW(m, lr=1e-2)
+    p0 = torch.cat([p.detach().flatten() for p in m.parameters()]).cpu()
+    loss, _, _ = m.elbo(xs, ys, None, M=2, eps=eps[:, rank * 2:(rank + 1) * 2].contiguous().to(dev))
+    opt.zero_grad(); loss.backward(); opt.step()
+    p1 = torch.cat([p.detach().flatten() for p in m.parameters()]).cpu()
+    torch.save(dict(p0=p0, p1=p1, flag=float(m._last_scalars[L.PU_S_NONFINITE])), os.path.join(outdir, f"o{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overflow_on_one_rank_makes_every_rank_skip():
+    """f16 engine, rank 1 overflows (absurd loss scale), rank 0 does not: the flag is MAX-reduced with the gradients, so both
+    ranks leave their (identical) parameters untouched instead of rank 0 applying a NaN-poisoned average."""
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker_overflow, args=(2, os.path.join(d, "init"), d), nprocs=2, join=True)
+        o0, o1 = torch.load(os.path.join(d, "o0.pt")), torch.load(os.path.join(d, "o1.pt"))
+    assert o0["flag"] == 1.0 and o1["flag"] == 1.0
+    assert torch.equal(o0["p0"], o0["p1"]) and torch.equal(o1["p0"], o1["p1"]) and torch.equal(o0["p1"], o1["p1"])
+    assert torch.isfinite(o0["p1"]).all()
+
+
 def test_two_rank_model_path_on_one_gpu():
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_worker, args=(2, os.path.join(d, "init"), d), nprocs=2, join=True)
