@@ -324,3 +324,29 @@ def test_f16_overflow_is_flagged_and_the_step_skipped_on_device():
             assert torch.equal(before, after) and float(opt.exp_avg.abs().sum()) == 0.0
         else:
             assert not torch.equal(before, after) and torch.isfinite(after).all()
+
+
+@pytest.mark.parametrize("H,W", [(48, 80), (16, 144)])
+def test_mixed_kernel_paths_on_odd_geometries(H, W):
+    """Sizes whose levels fall on different convolution paths (16x16-tile conv3 at the top, the LDS-staged 8x8-tile kernel
+    below; GroupNorm statistics from the conv epilogue at one level, from the stand-alone pass at the other): fp32 engine at
+    the parity tolerance, f16 engine by feature error and gradient cosine."""
+    cfg = O.Config(2, 1, 4, [8, 16], 8, [1, 2])
+    P = filled_params(cfg)
+    x, y = make_fields(2, 2, 1, H, W, seed=17); eps = make_eps(2, 2, 4)
+    r, og = O.elbo_with_grads(P, cfg, x, y, eps, beta0=0.7, beta1=1.3)
+    gref = torch.cat([og[k].flatten() for k in sorted(og)]).double()
+    for dtype in ("f32", "f16"):
+        m = pa.ProbabilisticUNet(2, 1, 4, [8, 16], 8, [1, 2], 0.7, 1.3, 0.0, dtype=dtype, init=False)
+        m.load_state_dict(P); m = m.to(DEV).train(); m.dropout = 0.0
+        total, recon, kl = m.elbo(x.to(DEV), y.to(DEV), None, M=2, eps=eps.to(DEV))
+        total.backward()
+        g = torch.cat([dict(m.named_parameters())[k].grad.flatten().cpu() for k in sorted(og)]).double()
+        cos = float(g @ gref / (g.norm() * gref.norm()))
+        with torch.no_grad():
+            feat = m.unet(x.to(DEV)).cpu()
+        if dtype == "f32":
+            assert_close(total.detach().cpu(), r["total"], what="total"); assert_close(feat, r["feat"], what="feat")
+            assert cos > 0.99999, cos
+        else:
+            assert float((feat - r["feat"]).abs().max()) < 3e-2 * float(r["feat"].abs().max()) + 1e-2 and cos > 0.995, cos
