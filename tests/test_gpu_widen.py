@@ -350,3 +350,26 @@ def test_mixed_kernel_paths_on_odd_geometries(H, W):
             assert cos > 0.99999, cos
         else:
             assert float((feat - r["feat"]).abs().max()) < 3e-2 * float(r["feat"].abs().max()) + 1e-2 and cos > 0.995, cos
+
+
+def test_engine_regrowth_keeps_parameters_gradients_and_optimizer_state():
+    """The static plan is sized for a maximum batch; a larger batch re-creates the engine.  Parameters, their flat aliasing and the
+    optimizer moments must survive that (both optimizers), and the smaller batch must keep working afterwards."""
+    for make_opt in (lambda m: pa.FlatAdamW(m, lr=1e-3), lambda m: torch.optim.AdamW(m.parameters(), lr=1e-3)):
+        m, cfg, P = _small_model("afcrps", dtype="f16", H=32)
+        m.train(); m.dropout = 0.0
+        opt = make_opt(m)
+        losses = []
+        for B in (2, 2, 5, 3, 5):
+            x, y = make_fields(B, 2, 1, 32, 32, seed=18)
+            loss, _, _ = m.elbo(x.to(DEV), y.to(DEV), None, M=2, eps=make_eps(2, B, 4).to(DEV))
+            opt.zero_grad(); loss.backward(); opt.step()
+            losses.append(float(loss.detach()))
+            assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+        assert all(np.isfinite(losses)), losses
+        ref, _, _ = _small_model("afcrps", dtype="f16", H=32)
+        moved = sum(float((p.detach() - q.detach()).abs().sum()) for p, q in zip(m.parameters(), ref.parameters()))
+        assert moved > 0.0
+        # every parameter is still a view of the engine's flat buffer
+        base = m._flat.data_ptr(); end = base + m._flat.numel() * 4
+        assert all(base <= p.data_ptr() < end for p in m.parameters())
