@@ -373,3 +373,23 @@ def test_engine_regrowth_keeps_parameters_gradients_and_optimizer_state():
         # every parameter is still a view of the engine's flat buffer
         base = m._flat.data_ptr(); end = base + m._flat.numel() * 4
         assert all(base <= p.data_ptr() < end for p in m.parameters())
+
+
+def test_gradient_accumulation_across_backward_calls():
+    """autograd semantics of p.grad: a second backward without zero_grad adds; (2 * loss).backward() doubles."""
+    m, cfg, P = _small_model("afcrps", H=32)
+    m.train(); m.dropout = 0.0
+    x, y = make_fields(2, 2, 1, 32, 32, seed=19); x, y = x.to(DEV), y.to(DEV); eps = make_eps(2, 2, 4).to(DEV)
+    def flat():
+        return torch.cat([p.grad.flatten() for p in m.parameters()]).clone()
+    def same(a, b):                                        # float-atomic parameter gradients: order noise at the 1e-6 level
+        return float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())
+    l, _, _ = m.elbo(x, y, None, M=2, eps=eps); l.backward(); g1 = flat()
+    l, _, _ = m.elbo(x, y, None, M=2, eps=eps); l.backward(); g2 = flat()
+    assert same(g2, 2 * g1)
+    m.zero_grad(set_to_none=True)
+    l, _, _ = m.elbo(x, y, None, M=2, eps=eps); (2.0 * l).backward(); g3 = flat()
+    assert same(g3, 2 * g1)
+    m.zero_grad(set_to_none=False)                         # zeros in place: the next backward accumulates into them
+    l, _, _ = m.elbo(x, y, None, M=2, eps=eps); l.backward()
+    assert same(flat(), g1)
