@@ -11,6 +11,13 @@ train mode (dropout 0.1), followed by the AdamW(lr=1e-4) step of the reference t
 (train_prob_unet_model.py:133-141) — the optimizer step and, for N > 1, the RCCL gradient all-reduce are INSIDE the
 timed region.  Synthetic ClimEx-shaped fields, inputs resident in HBM before timing starts.
 
+Loss weights: the reference starts training at beta_0 = 1, beta_1 = 0 (src/main.py:109-110, two warm-up epochs without the KL
+penalty, then a linear ramp, :141-155); the bench runs that first-epoch setting.  The KL forward and the whole backward of both
+latent encoders still execute (the engine has no beta-dependent shortcut), so the work per step is that of any other beta.
+
+--gpus N > 1 without an external launcher: the script starts `python -m torch.distributed.run --nproc-per-node N` on itself
+BEFORE anything touches the GPU and relays the child's output and exit code.
+
 One JSON line is printed by rank 0 with the contract fields plus `roofline` (dominant kernel: the 3x3 implicit-GEMM
 MFMA convolution, timed live with HIP events on its launch stream through pu_profile_*) and, at N=1, `cpu_baseline`
 (the torch-CPU oracle on a bounded sample of the same workload, host cores of this box).
@@ -52,11 +59,11 @@ def perturb_zero_init(model, seed=7):
                 p.copy_((torch.randn(p.shape, generator=g) * (0.5 / fan_in ** 0.5)).to(p.device))
 
 
-def build_model(cfg, dtype, device, recon="afcrps"):
+def build_model(cfg, dtype, device, recon="afcrps", beta_1=0.0):
     import probunet_amd as pa
     torch.manual_seed(42)
     m = pa.ProbabilisticUNet(cfg["input_channels"], cfg["num_classes"], cfg["latent_dim"], cfg["num_filters"], cfg["model_channels"],
-                             cfg["channel_mult"], 1.0, 1.0, 0.0, dtype=dtype, max_batch=cfg["batch"], max_members=cfg["M"], recon=recon)
+                             cfg["channel_mult"], 1.0, beta_1, 0.0, dtype=dtype, max_batch=cfg["batch"], max_members=cfg["M"], recon=recon)
     perturb_zero_init(m)
     return m.to(device).train()
 
@@ -99,45 +106,73 @@ def cpu_baseline(cfg, seconds_budget=25.0):
         if time.time() - t_all > seconds_budget and times:
             break
     med = sorted(times)[len(times) // 2]
-    return dict(value=round(B * frac / med, 4), unit="field-pairs/s", cores=cores, kind="port",
+    # cfg1 EXACTLY (1 -> 1 planes, 64 x 64 N(0,1) fields, depth-3 U-Net [32, 64, 128], latent 6, B = 4, M = 5, train mode
+    # with injected dropout masks), 3 warm-up + 10 timed steps, median - a measurement, not an extrapolation (unit: 64 x 64 pairs/s)
+    c1 = O.Config(1, 1, 6, [32, 64, 128], 32, [1, 2, 4])
+    P1 = fill_state(O.param_shapes(c1))
+    g1 = torch.Generator().manual_seed(1234)
+    x1 = torch.randn(4, 1, 64, 64, generator=g1); y1 = torch.randn(4, 1, 64, 64, generator=g1); e1 = torch.randn(5, 4, 6, generator=g1)
+    enc1, dec1 = O.unet_layout(c1)
+    t1 = []
+    for it in range(13):
+        masks = {b.name: (torch.rand(4, b.cout, 64 * int(b.name.split(".")[2].split("x")[0]) // 128, 64 * int(b.name.split(".")[2].split("x")[0]) // 128)
+                          >= c1.dropout).float() for b in enc1 + dec1 if b.kind == "block"}
+        t0 = time.time()
+        O.elbo_with_grads(P1, c1, x1, y1, e1, beta0=1.0, beta1=1.0, drop_masks=masks)
+        if it >= 3:
+            t1.append(time.time() - t0)
+    med1 = sorted(t1)[len(t1) // 2]
+    cfg1_exact = dict(value=round(4 / med1, 2), unit="64x64 field-pairs/s", steps=len(t1), median_s_per_step=round(med1, 4),
+                      sample="BASELINE cfg1 exactly: 1->1, 64x64, depth-3, latent 6, B=4, afCRPS-ELBO M=5 fwd+bwd, fp32 torch-CPU oracle")
+    return dict(value=round(B * frac / med, 4), unit="field-pairs/s", cores=cores, kind="port", cfg1_exact=cfg1_exact,
                 sample=f"cfg3 network + afCRPS-ELBO M={cfg['M']} fwd+bwd, fp32 torch-CPU oracle, batch 1, one {crop}x{crop} crop "
                        f"(= {frac:.4f} of a 256x256 pair; value = crop rate x {frac:.4f}), {len(times)} timed step(s) after 1 warm-up, "
                        f"median {med:.2f} s per crop step, {cores} threads")
 
 
 def pmc_traffic(kernel_tag):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/r1_pmc_traffic.json:
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/r2_pmc_traffic.json:
     FETCH_SIZE x 2 (gfx950 correction, MI355X_MICROARCH.md §HBM) + WRITE_SIZE, KiB -> bytes).  None if not collected."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")) as f:
             t = json.load(f)
         return t.get(kernel_tag, {}).get("hbm_bytes_per_launch")
     except Exception:
         return None
 
 
-def bench_sample(args):
-    """BASELINE config 5 (secondary metric): inference-only latent exploration, 256x256, `samples` prior samples per input."""
+def bench_sample(args, steps=None, warmup=None, inputs=None, graph=True):
+    """BASELINE config 5 (secondary metric): inference-only latent exploration, 256x256, `samples` prior samples per lo-res input,
+    hipGraph-captured U-Net + prior + samples x Fcomb (pu_set_sample_graph).  Output buffers are preallocated by the caller-side
+    allocator of torch, so the captured graph's pointers repeat from call to call."""
     device = torch.device("cuda", 0)
     torch.cuda.set_device(0)
-    B = args.batch if args.batch != CFG3["batch"] else 8
+    steps = args.steps if steps is None else steps
+    warmup = max(3, args.warmup if warmup is None else warmup)       # call 1 eager, call 2 captures, call 3+ replay
+    B = inputs if inputs is not None else (args.batch if args.mode == "sample" and args.batch != CFG3["batch"] else 32)
     cfg = dict(CFG3, batch=B, M=args.samples)
     model = build_model(cfg, args.dtype, device).eval()
+    model.use_sample_graph = graph
     model.assume_static_parameters = True            # inference: the compute-dtype weight copies are packed once, not per call
     x, _ = synthetic_fields(B, cfg["input_channels"], cfg["num_classes"], cfg["H"], cfg["W"], 4321, device)
+    eps = torch.randn(args.samples, B, cfg["latent_dim"], device=device)          # resident noise: the graph reads it in place
     if args.hr:       # physical-unit fields: residual_to_hr fused into the Fcomb store (row f3)
         lrinterp = x[:, : cfg["num_classes"]].contiguous(); std = torch.rand(cfg["num_classes"], cfg["H"], cfg["W"], device=device) + 0.5
-        draw = lambda: model.sample_hr(x, args.samples, lrinterp, std)
+        draw = lambda: model.sample_hr(x, args.samples, lrinterp, std, eps=eps)
     else:
-        draw = lambda: model.sample(x, args.samples)
-    for _ in range(args.warmup):
-        draw()
+        draw = lambda: model.sample(x, args.samples, eps=eps)
+    out = None
+    for _ in range(warmup):
+        out = None                                   # release the previous output first: the allocator hands the same block back
+        out = draw()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
+        out = None
         out = draw()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
+    finite = bool(torch.isfinite(out).all())
     # Fcomb-only rate (features and prior fixed, the inner loop of latent_exploration.py:119-129)
     with torch.no_grad():
         feat = model.unet(x[:1])
@@ -148,12 +183,33 @@ def bench_sample(args):
         for _ in range(20):
             model.fcomb(feat.expand(args.samples, -1, -1, -1), z)
         torch.cuda.synchronize(); el2 = time.perf_counter() - t1
-    print(json.dumps(dict(metric="prior samples/sec at 256x256 (64 samples per lo-res input)", value=round(B * args.samples * args.steps / el, 1),
-                          unit="samples/s", n_gpus=1, steps=args.steps, warmup=args.warmup, ms_per_step=round(1e3 * el / args.steps, 3),
-                          higher_is_better=True, scaling="weak", vs_baseline=None, dtype=args.dtype, data="synthetic",
-                          config=dict(workload=f"cfg5: 4->1, 256x256, latent 12, depth-5 U-Net, {B} inputs x {args.samples} prior samples per call "
-                                               "(U-Net + prior once, then the fused Fcomb per sample)" + (" + fused residual_to_hr" if args.hr else ""),
-                                      fcomb_only_samples_per_s=round(args.samples * 20 / el2, 1)))), flush=True)
+    del model, out
+    torch.cuda.empty_cache()
+    return dict(metric="prior samples/sec at 256x256 (64 samples per lo-res input)", value=round(B * args.samples * steps / el, 1),
+                unit="samples/s", n_gpus=1, steps=steps, warmup=warmup, ms_per_step=round(1e3 * el / steps, 3),
+                higher_is_better=True, scaling="weak", vs_baseline=None, dtype=args.dtype, data="synthetic",
+                config=dict(workload=f"cfg5: 4->1, 256x256, latent 12, depth-5 U-Net, {B} inputs x {args.samples} prior samples per call "
+                                     "(U-Net + prior once, then the fused Fcomb per sample" + (", hipGraph replay)" if graph else ", eager launches)")
+                                     + (" + fused residual_to_hr" if args.hr else ""),
+                            hip_graph=bool(graph), outputs_finite=finite, fcomb_only_samples_per_s=round(args.samples * 20 / el2, 1)))
+
+
+def self_launch(n):
+    """python bench.py --gpus N with no launcher around it: become the parent of `torch.distributed.run` with one rank per GPU.
+    Nothing in this process has touched the GPU yet (importing torch does not), and the children are fresh processes - never an
+    exec of a process that initialised HIP."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    r = subprocess.run(cmd, env=env)
+    sys.exit(r.returncode)
 
 
 def main():
@@ -173,20 +229,26 @@ def main():
     ap.add_argument("--mode", default="train", choices=["train", "sample"],
                     help="sample = BASELINE config 5: prior samples/s, 64 samples per lo-res input (U-Net + prior once, 64 x Fcomb)")
     ap.add_argument("--samples", type=int, default=64)
+    ap.add_argument("--no-graph", action="store_true", help="sample mode: eager launches instead of the captured hipGraph (A/B)")
+    ap.add_argument("--no-secondary", action="store_true", help="train mode: skip the cfg5 sampling measurement appended as `secondary`")
     ap.add_argument("--hr", action="store_true", help="sample mode: emit physical-unit fields (fused residual_to_hr)")
+    ap.add_argument("--beta1", type=float, default=0.0,
+                    help="KL weight; 0 = the reference's first-epoch setting (main.py:109-110). The work per step does not depend on it")
+    ap.add_argument("--dp-buckets", type=int, default=4, help="N > 1: U-Net gradient buckets all-reduced under the backward (0 = one all-reduce)")
     ap.add_argument("--recon", default="afcrps", choices=["afcrps", "wmse_msssim", "l1"],
                     help="reconstruction term; afcrps is the reported metric, wmse_msssim is the reference's live elbo (diagnostic)")
     args = ap.parse_args()
     if args.mode == "sample":
-        return bench_sample(args)
+        print(json.dumps(bench_sample(args, graph=not args.no_graph)), flush=True)
+        return
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return self_launch(args.gpus)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} (or without a launcher)")
     import torch.distributed as dist
     # PU_BENCH_REHEARSAL=1: every rank on GPU 0 with the gloo backend - exercises the multi-rank control flow of this script on a
     # one-GPU box (RCCL refuses two ranks on one device).  Never used for reported numbers.
@@ -202,7 +264,8 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     cfg = dict(CFG3, batch=args.batch, M=args.members)
-    model = build_model(cfg, args.dtype, device, args.recon)
+    model = build_model(cfg, args.dtype, device, args.recon, args.beta1)
+    model.dp_overlap_buckets = args.dp_buckets
     model.sync_scalars = False                       # keep the loss scalars on the device: no .item() sync per step
     torch.manual_seed(1234 + rank)                   # rank-offset reparameterisation noise (dropout seeds are rank-offset inside the model)
     if world > 1:
@@ -247,6 +310,10 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     pairs_per_s = world * cfg["batch"] * args.steps / elapsed
     loss_val = float(loss.detach().item())
+    loss_finite = bool(loss_val == loss_val and abs(loss_val) != float("inf"))
+    if not loss_finite:
+        print(f"[bench] WARNING: the training loss is not finite after {args.warmup + args.steps} steps ({loss_val}); the throughput line "
+              "below describes a diverged workload", file=sys.stderr, flush=True)
 
     # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream (one extra step)
     from probunet_amd import _lib as L
@@ -271,7 +338,11 @@ def main():
             achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
             peak = PEAK[args.dtype] / 1e12
             roofline = dict(bound="mfma", kernel=d["name"], achieved=round(achieved, 2), peak=peak, unit="TFLOP/s",
-                            frac=round(achieved / peak, 4), traffic=pmc_traffic(d["name"]), launches_per_step=d["launches"],
+                            frac=round(achieved / peak, 4), traffic=pmc_traffic(d["name"]),
+                            traffic_source="profiles/r2_pmc_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this "
+                                           "command, committed; not collected in this run)",
+                            timing_source="HIP events on the kernel's launch stream, this run, side streams off",
+                            launches_per_step=d["launches"],
                             avg_launch_us=round(1e3 * d["ms"] / d["launches"], 2),
                             flops_per_launch=d["flops"] / d["launches"],
                             algorithmic_bytes_per_launch=d["bytes"] / d["launches"],
@@ -287,12 +358,24 @@ def main():
                                     + ("" if args.no_optimizer else (" + AdamW step (fused flat kernel)" if flat else " + torch AdamW step")) + (" + RCCL grad all-reduce" if world > 1 else ""),
                            global_batch=world * cfg["batch"], parallelism=f"dp{world}",
                            elbo_fwd_bwd_tflop_per_step=round(3 * fwd_flops / 1e12, 3),
-                           model_tflops=round(3 * fwd_flops * world / (elapsed / args.steps) / 1e12, 2), final_loss=loss_val),
+                           model_tflops=round(3 * fwd_flops * world / (elapsed / args.steps) / 1e12, 2),
+                           beta_0=1.0, beta_1=args.beta1, final_loss=loss_val if loss_finite else None, loss_finite=loss_finite,
+                           world_size_seen_by_backend=(dist.get_world_size() if world > 1 else 1),
+                           backend=(dist.get_backend() if world > 1 else None),
+                           dp_gradient_buckets=(len(model._dp_bucket_ranges()) if world > 1 else 0)),
                roofline=roofline)
+    if rank == 0 and world == 1 and not args.no_secondary:
+        # BASELINE config 5 beside the headline number (secondary metric): the training model is released first
+        del opt, model, x, y
+        torch.cuda.empty_cache()
+        try:
+            out["secondary"] = bench_sample(args, steps=10, warmup=3)
+        except Exception as e:                          # never lose the headline line over the secondary one
+            out["secondary"] = dict(error=f"{type(e).__name__}: {e}")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out, allow_nan=False), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -92,6 +92,15 @@ int pu_params_changed(pu_ctx* ctx);
 /* ---- sub-modules (replace model.unet(x), model.prior(x)/model.posterior(x,y), model.fcomb(f,z)) --------- */
 /* networks.py:299-333. x [B,Cin,H,W] -> feat [B,F0,H,W]. train!=0 enables dropout with drop_seed. */
 int pu_unet_fwd(pu_ctx*, const float* x, float* feat, int B, int train, uint64_t drop_seed, void* stream);
+/* Injected dropout masks ("the ABI must accept eps and a dropout seed/mask"; networks.py:177 draws them from
+ * torch's RNG, which no other implementation can reproduce): the U-Net has one dropout site per UNetBlock, in execution order
+ * (encoder blocks, then decoder blocks).  pu_drop_site describes site i (reference state_dict prefix of its block, C, H, W).
+ * pu_set_drop_masks takes the sites' keep masks concatenated in that order, each fp32 [B, C_i, H_i, W_i] (non-zero = keep); they
+ * replace the counter-hash stream in every later train-mode call (forward AND its backward) with batch size B until cleared
+ * with masks == NULL.  Kept elements are scaled by 1 / (1 - dropout_p) as F.dropout does. */
+int pu_drop_site_count(pu_ctx*);
+int pu_drop_site(pu_ctx*, int i, char name[96], int* C, int* H, int* W);
+int pu_set_drop_masks(pu_ctx*, const float* masks_or_null, int B, void* stream);
 /* backward of the LAST pu_unet_fwd: dfeat [B,F0,H,W] -> parameter grads ADDED into flat_grads (x needs no grad). */
 int pu_unet_bwd(pu_ctx*, const float* dfeat, void* stream);
 /* prob_unet.py:56-85. -> mu [B,L], log_sigma [B,L] (sigma = exp(log_sigma) + 1e-7 is the caller's). */
@@ -114,6 +123,19 @@ int pu_elbo_fwd_bwd(pu_ctx*, const float* x, const float* target, const float* e
                     float beta0, float beta1, float beta2, float alpha, int train, uint64_t drop_seed,
                     int with_backward, float* out_scalars, float* out_kl, float* out_kl2, void* stream);
 
+/* ---- data-parallel hand-off: the backward of pu_elbo_fwd_bwd finishes the flat gradient buffer in pieces, deepest
+ * decoder level first.  pu_grad_buckets reports up to `max` contiguous element ranges [lo, hi) of flat_grads in the order in which
+ * the LAST pu_elbo_fwd_bwd(with_backward) completes them (they partition [0, pu_param_count)); pu_grad_bucket_wait makes `stream`
+ * wait (hipStreamWaitEvent, no host sync) until every kernel writing bucket k has finished, so that a collective enqueued on that
+ * stream afterwards overlaps the rest of the backward.  pu_set_grad_buckets(n) chooses how many U-Net buckets the plan is cut
+ * into (0 = off: no events are recorded; default).  While buckets are on, the f16 overflow flag is NOT computed inside
+ * pu_elbo_fwd_bwd (the collective rewrites the buffer in place); use pu_nonfinite_flag on the averaged gradients instead. */
+int pu_set_grad_buckets(pu_ctx*, int n_unet_buckets);
+int pu_grad_buckets(pu_ctx*, int64_t* lo, int64_t* hi, int max, int* n);
+int pu_grad_bucket_wait(pu_ctx*, int k, void* stream);
+/* flag[0] = 1.0f if any of the n floats is inf / NaN, else unchanged (zero it first); ~60 us for the 76 M gradients of cfg3. */
+int pu_nonfinite_flag(const float* g, int64_t n, float* flag, void* stream);
+
 /* Location / scale [B, L] of the prior (PU_PRIOR) or posterior (PU_POSTERIOR) computed by the LAST forward of that encoder
  * (pu_elbo_fwd_bwd, pu_gauss_fwd or pu_sample): what the reference leaves behind in `self.prior_latent_space` /
  * `self.posterior_latent_space` (prob_unet.py:214,220,241-242). scale = exp(log_sigma) + 1e-7 (prob_unet.py:84). */
@@ -121,7 +143,12 @@ int pu_last_latent(pu_ctx*, int which, float* mu, float* sigma, int B, void* str
 
 /* ---- sampling (replaces n x model(x, training=False), train_prob_unet_model.py:244-247, and
  *      latent_exploration.py:119-129): U-Net + prior (or posterior if target given) ONCE, then n x Fcomb. ---- */
-/* eps [n,B,L]; out [B,n,Cout,H,W]; mu/sigma [B,L] nullable. */
+/* eps [n,B,L]; out [B,n,Cout,H,W]; mu/sigma [B,L] nullable.
+ * hipGraph: with pu_set_sample_graph(ctx, 1) the launch sequence of pu_sample / pu_sample_hr is captured once per distinct
+ * argument tuple (all pointers, B, n) and replayed with one hipGraphLaunch afterwards (BASELINE config 5: "hipGraph-captured
+ * sample+fcomb").  Parameters are read at replay time, so weight updates are seen as long as pu_params_changed is NOT pending
+ * (a pending re-pack runs eagerly before the replay).  Off by default; the captured graphs die with the ctx. */
+int pu_set_sample_graph(pu_ctx*, int on);
 int pu_sample(pu_ctx*, const float* x, const float* target_or_null, const float* eps, int B, int n,
               float* out, float* mu, float* sigma, void* stream);
 
@@ -151,6 +178,15 @@ int pu_lr_stats(const float* hr, int N, int C, int H, int W, int k, float* mean_
 int pu_lrinterp_to_residuals(const float* hr, int B, int C, int H, int W, int k, const float* mean_hr, const float* std_hr,
                              float epsilon, float* inputs, float* targets, float* lrinterp, float* lr, void* stream);
 
+/* climex_utils.softplus (:41-45, inverse = 0) / softplus_inv (:36-40, inverse != 0), in place on n floats like the reference:
+ *   softplus: v > threshold ? v : log(exp(v) + 1) - c;     softplus_inv: v > threshold ? v : log(exp(v + c) - 1). */
+int pu_softplus_transform(float* data, int64_t n, int inverse, float threshold, float c, void* stream);
+/* ClimExDataset.invstand_residual / residual_to_hr (climex_utils.py:270-285) on tensors that already exist:
+ *   out[b,s,c,:,:] = (base ? base[b,c,:,:] : 0) + x[b,s,c,:,:] * (std[c,:,:] + epsilon) + (mean ? mean[c,:,:] : 0)
+ * x, out [B,n,C,H,W]; base (lrinterp) [B,C,H,W] nullable; mean [C,H,W] nullable (the *_to_hr pipelines add it back). */
+int pu_destandardize(const float* x, const float* base, const float* std_hr, const float* mean_hr, float epsilon, int B, int n, int C,
+                     int H, int W, float* out, void* stream);
+
 /* ---- optimizer (replaces torch.optim.AdamW(model.parameters(), lr=1e-4).step(), main.py:103, train_prob_unet_model.py:141) on
  *      the flat buffers: one fused pass; exp_avg / exp_avg_sq are caller-owned fp32 arrays of n elements; step counts from 1. */
 int pu_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
@@ -160,6 +196,18 @@ int pu_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_
  * that address skips the poisoned step on the device, the way torch.cuda.amp.GradScaler does with a host sync. */
 int pu_adamw_step_guarded(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                           float beta2, float eps, float weight_decay, int64_t step, const float* skip_flag, void* stream);
+
+/* Same update with the step counter kept ON THE DEVICE: state is a device array of 4 floats, state[0] = number of updates applied
+ * so far (start at 0).  When skip_flag is non-zero nothing changes, the counter included, so the bias corrections follow the
+ * number of APPLIED updates exactly as torch.optim.AdamW under a GradScaler that skipped the step. */
+int pu_adamw_step_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
+                      float eps, float weight_decay, float* state, const float* skip_flag, void* stream);
+/* The two halves of pu_adamw_step_dev, for updating only SOME ranges of the flat buffers (torch.optim skips parameters whose
+ * .grad is None: no decay, no moment update): pu_adamw_prepare advances the counter once (unless skipped), then pu_adamw_apply
+ * runs the update on each contiguous range that has gradients (pointers already offset by the caller). */
+int pu_adamw_prepare(float* state, const float* skip_flag, float lr, float beta1, float beta2, void* stream);
+int pu_adamw_apply(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
+                   float eps, float weight_decay, const float* state, void* stream);
 
 /* ---- introspection for bench/roofline ------------------------------------------------------------------ */
 int64_t pu_workspace_bytes(pu_ctx*);
@@ -175,27 +223,8 @@ int pu_profile_enable(int on);
 int pu_set_overlap(pu_ctx* ctx, int on);
 int pu_profile_collect(pu_prof_entry* out, int max_entries);
 
-/* ---- single-op entry points (used by tests/ to pin each kernel against a torch fp32 reference) ----------- */
-/* 3x3 (ks=3) or 1x1 (ks=1) convolution on NCHW fp32 tensors through the engine's NHWC implicit-GEMM kernels in
- * `dtype`. mode 0: y = conv(x,w)+b (relu optional); 1: dx = dgrad(dy,w); 2: dw = wgrad(dy,x) (w/dw in [Cout,Cin,ks,ks]).
- * All pointers device fp32. Syncs the stream. */
-int pu_op_conv(int dtype, int mode, int ks, int relu, int B, int Cin, int Cout, int H, int W,
-               const float* x, const float* w, const float* bias, const float* dy, float* out, void* stream);
-/* Micro-benchmark: average microseconds (HIP events, `iters` back-to-back launches) of one convolution kernel launch on
- * NHWC data already in HBM. mode 0 forward, 1 data gradient, 2 weight gradient (incl. its slab reduce). Syncs. */
-int pu_bench_conv(int dtype, int mode, int ks, int B, int Cin, int Cout, int H, int W, int iters, float* out_us, void* stream);
-/* GroupNorm(+scale/shift)+SiLU(+dropout drop_p with the counter-hash mask of drop_seed; resample 0 only) with optional
- * 2x resample (0 none, 1 avg-pool down, 2 nearest up), forward and backward, on NCHW fp32 tensors. Syncs. */
-int pu_op_gnsilu(int dtype, int resample, int B, int C, int H, int W, const float* x, const float* gamma,
-                 const float* beta, const float* scale_shift_or_null, float* y,
-                 const float* dy_or_null, float* dx, float* dgamma, float* dbeta, float* dscale_shift,
-                 float drop_p, uint64_t drop_seed, void* stream);
-
-/* WMSE-MS-SSIM loss and its gradient on fp32 device tensors pred [B,M,C,H,W], target [B,C,H,W] (stand-alone test hook for
- * the kernels behind PU_RECON_WMSE_MSSSIM). out_scalars: PU_NUM_SCALARS floats (PU_S_RECON, PU_S_WMSE, PU_S_MSSSIM filled);
- * dpred (nullable) receives gscale * d(recon)/d(pred). Syncs. */
-int pu_op_wmse_msssim(const float* pred, const float* target, int B, int M, int C, int H, int W, float alpha_w, float beta_w,
-                      float lam_w, float data_range, float gscale, float* out_scalars, float* dpred, void* stream);
+/* The single-op test hooks and the convolution micro-benchmark (pu_op_*, pu_bench_conv) are NOT part of this ABI: they are
+ * declared in include/probunet_testing.h. */
 
 #ifdef __cplusplus
 }

@@ -34,6 +34,11 @@ captured from the *imported reference*, see tools/make_golden.py):
   src/prob_unet_utils.py:270-305 wmse_ms_ssim_loss                  -> wmse_ms_ssim_loss
   src/climex_utils.py:36-46,197-225,255-285 data transforms         -> softplus_climex, lrinterp_to_residuals, lr_stats, residual_to_hr
 
+The ClimEx transforms are PINNED too: tools/make_golden_climex.py imports src/climex_utils.py (absent xarray / dask / cartopy /
+bottleneck / cftime replaced by empty in-memory modules; the NetCDF constructor is not run) and captures softplus, softplus_inv,
+compute_stats, the item transform, invstand_residual and residual_to_hr into tests/golden/climex.npz
+(tests/test_oracle_golden.py::test_climex_transforms_match_reference).
+
 Parity status: PINNED by golden vectors generated from the reference import (no denial encountered), with ONE exception:
   ms_ssim() below restates the third-party dependency `pytorch-msssim==1.0.0` (pinned in uv.lock:786-794, imported at
   prob_unet_utils.py:8, called at :297 with win_size=7, size_average=True).  The package is absent from this image and cannot
@@ -43,8 +48,6 @@ Parity status: PINNED by golden vectors generated from the reference import (no 
   no padding, relu on the per-scale means, 2x2 average pooling with padding = size % 2).  Everything around it — the WMSE half,
   the lam-combination, the data_range inference, the ensemble-mean rule — IS pinned (tests/golden/wmse.json, captured from the
   imported reference with ms_ssim replaced by a recording constant).
-  The climex_utils transforms are four torch calls each (AvgPool2d, interpolate, mean/std, arithmetic); climex_utils itself
-  cannot be imported here (xarray absent), so they are restated from the source text and checked against those torch calls.
 """
 from __future__ import annotations
 
@@ -425,6 +428,18 @@ def wmse_ms_ssim_loss(pred: Tensor, target: Tensor, alpha: float = 0.007, beta: 
 def softplus_climex(d: Tensor, threshold: float = 20.0, c: float = 1e-7) -> Tensor:
     """climex_utils.py:41-45 (out of place)."""
     return torch.where(d > threshold, d, torch.log(torch.exp(d) + 1.0) - c)
+
+
+def softplus_inv_climex(d: Tensor, threshold: float = 20.0, c: float = 1e-7) -> Tensor:
+    """climex_utils.py:36-40 (out of place): the pre-transform applied to precipitation / tasmax - tasmin at load time."""
+    return torch.where(d > threshold, d, torch.log(torch.exp(d + c) - 1.0))
+
+
+def invstand_residual(x: Tensor, mean_hr: Tensor, std_hr: Tensor, kind: str = "lrinterp_to_residuals", epsilon: float = 1e-10) -> Tensor:
+    """climex_utils.py:270-274: the *_to_hr pipelines add the mean back, the *_to_residuals ones only rescale."""
+    if kind in ("lr_to_hr", "lrinterp_to_hr"):
+        return x * (std_hr + epsilon) + mean_hr
+    return x * (std_hr + epsilon)
 
 
 def lr_stats(hr: Tensor, k: int):

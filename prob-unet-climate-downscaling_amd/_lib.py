@@ -1,4 +1,5 @@
-"""ctypes binding of libprobunet.so (include/probunet.h). No CPU fallback: loading fails loudly."""
+"""ctypes binding of libprobunet.so (include/probunet.h; the pu_op_* / pu_bench_conv test hooks are declared in
+include/probunet_testing.h). No CPU fallback: loading fails loudly."""
 import ctypes as C
 import os
 
@@ -85,6 +86,20 @@ def lib():
     L.pu_adamw_step_guarded.restype = i32
     L.pu_adamw_step_guarded.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i64, vp, vp]
     L.pu_set_overlap.restype = i32; L.pu_set_overlap.argtypes = [vp, i32]
+    L.pu_adamw_step_dev.restype = i32
+    L.pu_adamw_step_dev.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, vp, vp]
+    L.pu_adamw_prepare.restype = i32; L.pu_adamw_prepare.argtypes = [vp, vp, f32, f32, f32, vp]
+    L.pu_adamw_apply.restype = i32; L.pu_adamw_apply.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, vp]
+    L.pu_nonfinite_flag.restype = i32; L.pu_nonfinite_flag.argtypes = [vp, i64, vp, vp]
+    L.pu_set_grad_buckets.restype = i32; L.pu_set_grad_buckets.argtypes = [vp, i32]
+    L.pu_grad_buckets.restype = i32; L.pu_grad_buckets.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), i32, C.POINTER(i32)]
+    L.pu_grad_bucket_wait.restype = i32; L.pu_grad_bucket_wait.argtypes = [vp, i32, vp]
+    L.pu_set_sample_graph.restype = i32; L.pu_set_sample_graph.argtypes = [vp, i32]
+    L.pu_drop_site_count.restype = i32; L.pu_drop_site_count.argtypes = [vp]
+    L.pu_drop_site.restype = i32; L.pu_drop_site.argtypes = [vp, i32, C.c_char_p, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    L.pu_set_drop_masks.restype = i32; L.pu_set_drop_masks.argtypes = [vp, vp, i32, vp]
+    L.pu_softplus_transform.restype = i32; L.pu_softplus_transform.argtypes = [vp, i64, i32, f32, f32, vp]
+    L.pu_destandardize.restype = i32; L.pu_destandardize.argtypes = [vp, vp, vp, vp, f32, i32, i32, i32, i32, i32, vp, vp]
     L.pu_profile_collect.restype = i32; L.pu_profile_collect.argtypes = [C.POINTER(PuProfEntry), i32]
     L.pu_op_conv.restype = i32
     L.pu_op_conv.argtypes = [i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]
@@ -107,6 +122,7 @@ def ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
-def current_stream():
+def current_stream(device=None):
+    """torch's current stream ON `device` (the model's device, which need not be torch's current device)."""
     import torch
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)

@@ -10,11 +10,12 @@
 #include <vector>
 
 #include "../../include/probunet.h"
+#include "../../include/probunet_testing.h"
 #include "pu_kernels.h"
 
 using namespace pu;
 
-#define PU_ABI 1
+#define PU_ABI 2
 
 namespace {
 
@@ -32,6 +33,7 @@ struct GNL {
   int64_t g_off = -1, b_off = -1, ss_off = -1;   // gamma, beta, affine.bias (scale|shift) offsets
   float* stat = nullptr; float* coef = nullptr;
   uint32_t drop_stream = 0; bool dropout = false; int resample = RS_NONE;
+  int drop_site = -1;                  // index into pu_ctx::drop_sites when this GroupNorm is followed by dropout
 };
 struct Act { TV v; TV g; int flag = -1; };          // value view, gradient view, index of the shared "grad written" flag
 
@@ -45,6 +47,8 @@ struct Block {
   // (conv1, or conv0 of the stem) and of `c0` (conv0); sl_* = slot count per image reported by the launcher for this forward
   float *st_out = nullptr, *st_c0 = nullptr; int cap_out = 0, cap_c0 = 0, sl_out = 0, sl_c0 = 0;
   int src0 = -1, src1 = -1;              // producers of x: index into enc (>= 0) or dec (1000 + j); src1 = skip half of a concat
+  int64_t p_lo = -1;                     // first flat parameter offset of this block
+  int bucket_close = -1;                 // gradient bucket whose last writer is this block's backward (data-parallel hand-off), or -1
 };
 struct GaussNet {
   std::vector<ConvL> convs; std::vector<Act> outs; std::vector<Act> ins;   // ins[i] is the input of conv i
@@ -84,6 +88,15 @@ struct pu_ctx {
   float wm_alpha = 0.007f, wm_beta = 0.048f, wm_lam = 0.f, wm_range = -1.f;     // wmse_ms_ssim_loss defaults (prob_unet.py:231-233)
   float* ms_ws = nullptr; size_t ms_ws_floats = 0;                              // MS-SSIM pyramid workspace, allocated on first use
   hipStream_t side = nullptr, side2 = nullptr; std::vector<hipEvent_t> evs; size_t ev_next = 0; bool side_dirty = false; bool use_side = true;
+  // injected dropout masks (parity tests): one site per UNetBlock in execution order
+  struct DropSite { std::string name; int C, H, W; size_t off; };
+  std::vector<DropSite> drop_sites; uint8_t* drop_masks = nullptr; size_t drop_masks_cap = 0; int drop_masks_B = 0;
+  // data-parallel hand-off: flat gradient ranges in completion order + the events that mark them complete
+  struct Bucket { int64_t lo = 0, hi = 0; hipEvent_t ev[3] = {nullptr, nullptr, nullptr}; bool rec[3] = {false, false, false}; };
+  int want_buckets = 0; std::vector<Bucket> buckets; std::vector<int64_t> cuts;      // cuts: descending flat offsets closing the U-Net buckets
+  // cfg5: captured launch sequences of pu_sample / pu_sample_hr
+  struct SampleGraph { std::vector<const void*> key; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
+  bool sample_graph_on = false; std::vector<SampleGraph> sample_graphs; std::vector<std::vector<const void*>> sample_seen;
 };
 
 static std::string g_create_err;
@@ -183,7 +196,7 @@ static int build_plan(pu_ctx* c) {
   const int mb = cf.max_batch, D = cf.depth, mc = cf.model_channels;
   const size_t esz = c->esz;
   c->table.clear(); c->nparams = 0; c->packed_elems = 0; c->descs.clear(); c->flags.clear();
-  c->enc.clear(); c->dec.clear(); c->arena_used = 0; c->max_gn_c = 0;
+  c->enc.clear(); c->dec.clear(); c->arena_used = 0; c->max_gn_c = 0; c->drop_sites.clear();
   c->prior = GaussNet(); c->post = GaussNet();
   const int emb = mc * 4;
   add_param(c, "unet.map_label.weight", {emb, 1});
@@ -245,6 +258,7 @@ static int build_plan(pu_ctx* c) {
       b.cap_out = oH * oW / 64; b.st_out = alloc_f32(c, (size_t)mb * b.cap_out * s.cout * 2);
       if (s.is_block) { b.cap_c0 = b.cap_out; b.st_c0 = alloc_f32(c, (size_t)mb * b.cap_c0 * s.cout * 2); }
     }
+    b.p_lo = c->nparams;
     if (!s.is_block) {
       const int64_t w = add_param(c, p + ".weight", {s.cout, s.cin, 3, 3});
       const int64_t bb = add_param(c, p + ".bias", {s.cout});
@@ -273,6 +287,12 @@ static int build_plan(pu_ctx* c) {
     setup_gn(c, b.n0, s.cin, (long)inH * inW, g0, b0, -1, rs, false, 0);
     setup_conv(c, b.conv0, s.cin, s.cout, 3, w0, bb0, true, oH, oW);
     setup_gn(c, b.n1, s.cout, (long)oH * oW, g1, b1, ab, RS_NONE, true, drop_stream++);
+    {
+      size_t off = 0;
+      if (!c->drop_sites.empty()) { const auto& q = c->drop_sites.back(); off = q.off + (size_t)q.C * q.H * q.W; }   // per-sample offsets
+      b.n1.drop_site = (int)c->drop_sites.size();
+      c->drop_sites.push_back({s.name, s.cout, oH, oW, off});
+    }
     setup_conv(c, b.conv1, s.cout, s.cout, 3, w1, bb1, true, oH, oW);
     b.a0 = alloc_act(c, mb, oH, oW, s.cin);
     b.c0 = alloc_act(c, mb, oH, oW, s.cout);
@@ -500,6 +520,8 @@ static GNArgs gn_args(pu_ctx* c, const GNL& n, TV x, TV y, int B, int train, uin
   a.scale = n.ss_off >= 0 ? P(c, n.ss_off) : nullptr; a.shift = n.ss_off >= 0 ? P(c, n.ss_off + n.C) : nullptr;
   a.resample = n.resample;
   a.drop_p = (n.dropout && train) ? c->cfg.dropout_p : 0.f; a.drop_seed = seed; a.drop_stream = n.drop_stream;
+  if (a.drop_p > 0.f && c->drop_masks && n.drop_site >= 0 && B == c->drop_masks_B)      // injected masks: [site][B][H][W][C] uint8
+    a.drop_mask = c->drop_masks + c->drop_sites[n.drop_site].off * (size_t)c->drop_masks_B;
   a.part = c->gn_part; a.stat = n.stat; a.coef = n.coef; a.nchunk = n.nchunk;
   return a;
 }
@@ -539,6 +561,46 @@ static int gn_bwd(pu_ctx* c, const GNL& n, TV x, TV y, TV dy, TV dx, int accumul
   a.dscale = n.ss_off >= 0 ? G(c, n.ss_off) : nullptr; a.dshift = n.ss_off >= 0 ? G(c, n.ss_off + n.C) : nullptr;
   a.part2 = c->gn_part2; a.coef2 = c->gn_coef2; a.inv_scale = c->inv_scale;
   CKH(launch_gn_bwd<T>(a, s));
+  return PU_OK;
+}
+
+// ------------------------------------------------------------------ data-parallel gradient buckets
+// The backward completes the flat gradient buffer from its top (out_conv) downwards: out, decoder blocks reversed, encoder blocks
+// reversed is exactly descending flat order, so the U-Net buckets are contiguous ranges cut at block boundaries; the two latent
+// encoders + Fcomb (the tail of the buffer) form one more bucket, finished on the second side stream.
+static void plan_buckets(pu_ctx* c) {
+  for (auto& b : c->enc) b.bucket_close = -1;
+  for (auto& b : c->dec) b.bucket_close = -1;
+  for (auto& q : c->buckets) for (auto& e : q.ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+  c->buckets.clear();
+  const int n = c->want_buckets;
+  if (n <= 0) return;
+  const int64_t unet_hi = c->prior.convs[0].w_off;          // first parameter after the U-Net
+  std::vector<Block*> order;
+  for (int j = (int)c->dec.size() - 1; j >= 0; --j) order.push_back(&c->dec[j]);
+  for (int i = (int)c->enc.size() - 1; i >= 1; --i) order.push_back(&c->enc[i]);     // enc[0] (stem) always closes the last bucket
+  int64_t hi = unet_hi; int k = 0;
+  for (Block* b : order) {
+    if (k >= n - 1) break;
+    const int64_t target = unet_hi - (int64_t)((double)unet_hi * (k + 1) / n);
+    if (b->p_lo <= target) {
+      pu_ctx::Bucket q; q.lo = b->p_lo; q.hi = hi; c->buckets.push_back(q);
+      b->bucket_close = (int)c->buckets.size() - 1; hi = b->p_lo; ++k;
+    }
+  }
+  { pu_ctx::Bucket q; q.lo = unet_hi; q.hi = c->nparams; c->buckets.push_back(q); }     // latent encoders + Fcomb
+  { pu_ctx::Bucket q; q.lo = 0; q.hi = hi; c->buckets.push_back(q); }                   // shallow encoder levels: closes with the backward
+  for (auto& q : c->buckets) for (auto& e : q.ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) e = nullptr;
+}
+// mark bucket k complete at this point of the enqueue order: everything already enqueued on `s` (and on the weight-gradient
+// side stream, and on `s2` when given) belongs to it or to an earlier bucket
+static int record_bucket(pu_ctx* c, int k, hipStream_t s, hipStream_t s2 = nullptr) {
+  if (k < 0 || k >= (int)c->buckets.size()) return PU_OK;
+  pu_ctx::Bucket& q = c->buckets[k];
+  q.rec[0] = q.rec[1] = q.rec[2] = false;
+  if (q.ev[0]) { CKH(hipEventRecord(q.ev[0], s)); q.rec[0] = true; }
+  if (c->use_side && c->side_dirty && q.ev[1]) { CKH(hipEventRecord(q.ev[1], c->side)); q.rec[1] = true; }
+  if (s2 && s2 != s && q.ev[2]) { CKH(hipEventRecord(q.ev[2], s2)); q.rec[2] = true; }
   return PU_OK;
 }
 
@@ -631,9 +693,13 @@ static int unet_backward(pu_ctx* c, hipStream_t s, Mid&& mid) {
   const int jmid = (int)c->dec.size() * 2 / 3;           // `mid` is enqueued after the first third of the decoder blocks
   for (int j = (int)c->dec.size() - 1; j >= 0; --j) {
     if ((r = block_bwd<T>(c, c->dec[j], B, train, seed, true, s))) return r;
+    if (c->dec[j].bucket_close >= 0 && (r = record_bucket(c, c->dec[j].bucket_close, s))) return r;
     if (j == jmid && (r = mid())) return r;
   }
-  for (int i = (int)c->enc.size() - 1; i >= 0; --i) if ((r = block_bwd<T>(c, c->enc[i], B, train, seed, i > 0, s))) return r;
+  for (int i = (int)c->enc.size() - 1; i >= 0; --i) {
+    if ((r = block_bwd<T>(c, c->enc[i], B, train, seed, i > 0, s))) return r;
+    if (c->enc[i].bucket_close >= 0 && (r = record_bucket(c, c->enc[i].bucket_close, s))) return r;
+  }
   return PU_OK;
 }
 
@@ -708,8 +774,10 @@ int pu_create(const pu_config* cfg, int device, pu_ctx** out) {
   c->planning = true;
   int r = build_plan(c);
   if (r != PU_OK) return bail(r);
-  hipError_t e = hipSetDevice(device);
-  if (e != hipSuccess) { c->err = std::string("hipSetDevice: ") + hipGetErrorString(e); return bail(PU_ERR_HIP); }
+  DeviceGuard dg(device);                                  // the caller's current device is restored on every return path
+  int cur_dev = -1;
+  hipError_t e = hipGetDevice(&cur_dev);
+  if (e != hipSuccess || cur_dev != device) { c->err = std::string("hipSetDevice(") + std::to_string(device) + ") failed"; return bail(PU_ERR_HIP); }
   c->arena_size = c->arena_used + 4096;
   if ((e = hipMalloc(&c->arena, c->arena_size)) != hipSuccess) { c->err = std::string("hipMalloc(arena): ") + hipGetErrorString(e); return bail(PU_ERR_NOMEM); }
   if ((e = hipMemset(c->arena, 0, c->arena_size)) != hipSuccess) { c->err = "hipMemset(arena)"; (void)hipFree(c->arena); return bail(PU_ERR_HIP); }
@@ -735,6 +803,10 @@ int pu_create(const pu_config* cfg, int device, pu_ctx** out) {
 
 int pu_destroy(pu_ctx* c) {
   if (!c) return PU_OK;
+  DeviceGuard dg(c->device);
+  for (auto& g : c->sample_graphs) { if (g.exec) (void)hipGraphExecDestroy(g.exec); if (g.graph) (void)hipGraphDestroy(g.graph); }
+  for (auto& q : c->buckets) for (auto& e : q.ev) if (e) (void)hipEventDestroy(e);
+  if (c->drop_masks) (void)hipFree(c->drop_masks);
   for (auto e : c->evs) if (e) (void)hipEventDestroy(e);
   if (c->side) (void)hipStreamDestroy(c->side);
   if (c->side2) (void)hipStreamDestroy(c->side2);
@@ -808,6 +880,7 @@ static int check_B(pu_ctx* c, int B) {
 
 int pu_unet_fwd(pu_ctx* c, const float* x, float* feat, int B, int train, uint64_t seed, void* stream) {
   if (!c || !x) return PU_ERR_INVALID;
+  DeviceGuard dg(c->device);
   int r; if ((r = check_B(c, B))) return r;
   hipStream_t s = (hipStream_t)stream;
   if ((r = ensure_packed(c, s))) return r;
@@ -822,6 +895,7 @@ int pu_unet_fwd(pu_ctx* c, const float* x, float* feat, int B, int train, uint64
 }
 int pu_unet_bwd(pu_ctx* c, const float* dfeat, void* stream) {
   if (!c || !dfeat) return PU_ERR_INVALID;
+  DeviceGuard dg(c->device);
   if (!c->grads) FAIL(PU_ERR_STATE, "no gradient buffer bound");
   hipStream_t s = (hipStream_t)stream;
   return dispatch(c, [&](auto t) -> int {
@@ -847,6 +921,7 @@ static int gauss_input(pu_ctx* c, int which, const float* x, const float* target
 
 int pu_gauss_fwd(pu_ctx* c, int which, const float* x, const float* target, float* mu, float* ls, int B, void* stream) {
   if (!c || !x || (which == PU_POSTERIOR && !target)) return PU_ERR_INVALID;
+  DeviceGuard dg(c->device);
   int r; if ((r = check_B(c, B))) return r;
   hipStream_t s = (hipStream_t)stream;
   if ((r = ensure_packed(c, s))) return r;
@@ -861,6 +936,7 @@ int pu_gauss_fwd(pu_ctx* c, int which, const float* x, const float* target, floa
 }
 int pu_gauss_bwd(pu_ctx* c, int which, const float* dmu, const float* dls, void* stream) {
   if (!c || !dmu || !dls) return PU_ERR_INVALID;
+  DeviceGuard dg(c->device);
   if (!c->grads) FAIL(PU_ERR_STATE, "no gradient buffer bound");
   hipStream_t s = (hipStream_t)stream;
   GaussNet& g = which == PU_PRIOR ? c->prior : c->post;
@@ -874,6 +950,7 @@ int pu_gauss_bwd(pu_ctx* c, int which, const float* dmu, const float* dls, void*
 
 int pu_fcomb_fwd(pu_ctx* c, const float* feat, int64_t bstride, const float* z, float* out, int B, void* stream) {
   if (!c || !feat || !z || !out) return PU_ERR_INVALID;
+  DeviceGuard dg(c->device);
   int r; if ((r = check_B(c, B))) return r;
   if (!c->params) FAIL(PU_ERR_STATE, "pu_bind_params has not been called");
   hipStream_t s = (hipStream_t)stream;
@@ -893,6 +970,7 @@ int pu_fcomb_fwd(pu_ctx* c, const float* feat, int64_t bstride, const float* z, 
 }
 int pu_fcomb_bwd(pu_ctx* c, const float* dout, float* dfeat, float* dz, void* stream) {
   if (!c || !dout) return PU_ERR_INVALID;
+  DeviceGuard dg(c->device);
   if (!c->grads) FAIL(PU_ERR_STATE, "no gradient buffer bound");
   if (c->fc_B <= 0) FAIL(PU_ERR_STATE, "pu_fcomb_bwd without pu_fcomb_fwd");
   hipStream_t s = (hipStream_t)stream;
@@ -915,6 +993,7 @@ int pu_elbo_fwd_bwd(pu_ctx* c, const float* x, const float* target, const float*
                     float beta0, float beta1, float beta2, float alpha, int train, uint64_t seed, int with_backward,
                     float* out_scalars, float* out_kl, float* out_kl2, void* stream) {
   if (!c || !x || !target || !eps) return PU_ERR_INVALID;
+  DeviceGuard dg(c->device);
   int r; if ((r = check_B(c, B))) return r;
   if (M < 1 || M > c->cfg.max_members) FAIL(PU_ERR_INVALID, "M=%d outside [1, max_members=%d]", M, c->cfg.max_members);
   if (recon_kind == PU_RECON_AFCRPS && M < 2) FAIL(PU_ERR_INVALID, "M must be at least 2 to compute afCRPS but got M=%d", M);
@@ -996,11 +1075,14 @@ int pu_elbo_fwd_bwd(pu_ctx* c, const float* x, const float* target, const float*
     if ((q = unet_backward<T>(c, s, [&]() -> int {
           int e;
           if ((e = gauss_backward<T>(c, c->post, s2))) return e;
-          return gauss_backward<T>(c, c->prior, s2);
+          if ((e = gauss_backward<T>(c, c->prior, s2))) return e;
+          // latent encoders + Fcomb: complete once s2 and the weight gradients enqueued so far have run
+          return c->buckets.empty() ? PU_OK : record_bucket(c, (int)c->buckets.size() - 2, s, s2);
         }))) return q;
     if ((q = join2(c, s, s2))) return q;
     if ((q = join_side(c, s))) return q;
-    if (c->dt == PU_F16) {
+    if (!c->buckets.empty() && (q = record_bucket(c, (int)c->buckets.size() - 1, s))) return q;
+    if (c->dt == PU_F16 && c->buckets.empty()) {
       // fp16 activations can overflow (diverging training, a loss scale set too high): flag non-finite parameter gradients so
       // that the optimizer step can be skipped on the device (pu_adamw_step_guarded); one read of the flat buffer, ~60 us
       CKH(launch_nonfinite_flag(c->grads, (long)c->nparams, c->scal + PU_S_NONFINITE, s));
@@ -1017,6 +1099,7 @@ __global__ void export_mu_sigma_kernel(const float* mu, const float* ls, float* 
 
 int pu_last_latent(pu_ctx* c, int which, float* mu, float* sigma, int B, void* stream) {
   if (!c || (!mu && !sigma)) return PU_ERR_INVALID;
+  DeviceGuard dg(c->device);
   GaussNet& g = which == PU_POSTERIOR ? c->post : c->prior;
   if (g.lastB <= 0) FAIL(PU_ERR_STATE, "no forward of that latent encoder yet");
   if (B != g.lastB) FAIL(PU_ERR_INVALID, "B=%d but the last forward of that encoder had %d samples", B, g.lastB);
@@ -1025,13 +1108,8 @@ int pu_last_latent(pu_ctx* c, int which, float* mu, float* sigma, int B, void* s
   return hipGetLastError() == hipSuccess ? PU_OK : PU_ERR_HIP;
 }
 
-static int sample_impl(pu_ctx* c, const float* x, const float* target, const float* eps, int B, int n, float* out, float* mu, float* sigma,
-                       const float* lrinterp, const float* resid_std, float epsilon, int softplus, float softplus_c, void* stream) {
-  if (!c || !x || !eps || !out) return PU_ERR_INVALID;
-  int r; if ((r = check_B(c, B))) return r;
-  if (n < 1 || n > c->cfg.max_members) FAIL(PU_ERR_INVALID, "n=%d outside [1, max_members=%d]", n, c->cfg.max_members);
-  hipStream_t s = (hipStream_t)stream;
-  if ((r = ensure_packed(c, s))) return r;
+static int sample_body(pu_ctx* c, const float* x, const float* target, const float* eps, int B, int n, float* out, float* mu, float* sigma,
+                       const float* lrinterp, const float* resid_std, float epsilon, int softplus, float softplus_c, hipStream_t s) {
   const pu_config& cf = c->cfg;
   const long HW = (long)cf.H * cf.W; const int L = cf.latent_dim, ci = cf.input_channels;
   return dispatch(c, [&](auto t) -> int {
@@ -1051,6 +1129,129 @@ static int sample_impl(pu_ctx* c, const float* x, const float* target, const flo
     if (mu || sigma) hipLaunchKernelGGL(export_mu_sigma_kernel, dim3(cdiv((long)B * L, 256)), dim3(256), 0, s, g.mu, g.ls, mu, sigma, B * L);
     return PU_OK;
   });
+}
+
+static int sample_impl(pu_ctx* c, const float* x, const float* target, const float* eps, int B, int n, float* out, float* mu, float* sigma,
+                       const float* lrinterp, const float* resid_std, float epsilon, int softplus, float softplus_c, void* stream) {
+  if (!c || !x || !eps || !out) return PU_ERR_INVALID;
+  DeviceGuard dg(c->device);
+  int r; if ((r = check_B(c, B))) return r;
+  if (n < 1 || n > c->cfg.max_members) FAIL(PU_ERR_INVALID, "n=%d outside [1, max_members=%d]", n, c->cfg.max_members);
+  hipStream_t s = (hipStream_t)stream;
+  if ((r = ensure_packed(c, s))) return r;                 // eager, never inside a capture (the weights may have changed)
+  auto eager = [&]() { return sample_body(c, x, target, eps, B, n, out, mu, sigma, lrinterp, resid_std, epsilon, softplus, softplus_c, s); };
+  if (!c->sample_graph_on || !c->side2 || prof_enabled()) return eager();
+  // ---- hipGraph path: the first call with a given argument tuple runs eagerly (it also performs the one-time
+  // hipFuncSetAttribute calls, which are illegal inside a capture), the second captures, later ones replay
+  union { float f; uintptr_t u; } e0, e1; e0.u = 0; e1.u = 0; e0.f = epsilon; e1.f = softplus_c;
+  std::vector<const void*> key = {x, target, eps, out, mu, sigma, lrinterp, resid_std, (const void*)(uintptr_t)B, (const void*)(uintptr_t)n,
+                                  (const void*)(uintptr_t)softplus, (const void*)e0.u, (const void*)e1.u};
+  for (auto& g : c->sample_graphs) if (g.key == key) { CKH(hipGraphLaunch(g.exec, s)); c->unet_B = B; return PU_OK; }
+  bool seen = false;
+  for (auto& k : c->sample_seen) if (k == key) { seen = true; break; }
+  if (!seen) { if (c->sample_seen.size() >= 64) c->sample_seen.clear(); c->sample_seen.push_back(key); return eager(); }
+  // capture on the (otherwise idle, non-blocking) second side stream: torch's current stream is often the legacy default
+  // stream, which cannot be captured; the instantiated graph is launched on the caller's stream
+  hipStream_t cs = c->side2;
+  if (hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); return eager(); }
+  const int rb = sample_body(c, x, target, eps, B, n, out, mu, sigma, lrinterp, resid_std, epsilon, softplus, softplus_c, cs);
+  hipGraph_t graph = nullptr;
+  const hipError_t ee = hipStreamEndCapture(cs, &graph);
+  if (rb != PU_OK || ee != hipSuccess || !graph) { if (graph) (void)hipGraphDestroy(graph); (void)hipGetLastError(); return rb != PU_OK ? rb : eager(); }
+  hipGraphExec_t exec = nullptr;
+  if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess || !exec) { (void)hipGraphDestroy(graph); (void)hipGetLastError(); return eager(); }
+  if (c->sample_graphs.size() >= 8) {                       // bounded cache: drop the oldest
+    auto& o = c->sample_graphs.front();
+    (void)hipGraphExecDestroy(o.exec); (void)hipGraphDestroy(o.graph);
+    c->sample_graphs.erase(c->sample_graphs.begin());
+  }
+  pu_ctx::SampleGraph sg; sg.key = key; sg.graph = graph; sg.exec = exec;
+  c->sample_graphs.push_back(sg);
+  CKH(hipGraphLaunch(exec, s));
+  return PU_OK;
+}
+int pu_set_sample_graph(pu_ctx* c, int on) {
+  if (!c) return PU_ERR_INVALID;
+  c->sample_graph_on = on != 0;
+  return PU_OK;
+}
+int pu_drop_site_count(pu_ctx* c) { return c ? (int)c->drop_sites.size() : -1; }
+int pu_drop_site(pu_ctx* c, int i, char name[96], int* C, int* H, int* W) {
+  if (!c || i < 0 || i >= (int)c->drop_sites.size()) return PU_ERR_INVALID;
+  const auto& q = c->drop_sites[i];
+  if (name) snprintf(name, 96, "%s", q.name.c_str());
+  if (C) *C = q.C; if (H) *H = q.H; if (W) *W = q.W;
+  return PU_OK;
+}
+int pu_set_drop_masks(pu_ctx* c, const float* masks, int B, void* stream) {
+  if (!c) return PU_ERR_INVALID;
+  DeviceGuard dg(c->device);
+  if (!masks) { c->drop_masks_B = 0; return PU_OK; }        // back to the counter-hash stream (the buffer is kept for reuse)
+  int r; if ((r = check_B(c, B))) return r;
+  if (c->drop_sites.empty()) return PU_OK;
+  const auto& last = c->drop_sites.back();
+  const size_t per = last.off + (size_t)last.C * last.H * last.W, need = per * (size_t)B;
+  if (need > c->drop_masks_cap) {
+    if (c->drop_masks) { CKH(hipStreamSynchronize((hipStream_t)stream)); (void)hipFree(c->drop_masks); c->drop_masks = nullptr; c->drop_masks_cap = 0; }
+    if (hipMalloc(&c->drop_masks, need) != hipSuccess) { c->drop_masks = nullptr; FAIL(PU_ERR_NOMEM, "hipMalloc(dropout masks, %zu bytes)", need); }
+    c->drop_masks_cap = need;
+  }
+  for (const auto& q : c->drop_sites) {
+    const size_t site = (size_t)q.C * q.H * q.W;
+    CKH(launch_mask_to_nhwc_u8(masks + q.off * (size_t)B, c->drop_masks + q.off * (size_t)B, B, q.C, (long)q.H * q.W, (hipStream_t)stream));
+    (void)site;
+  }
+  c->drop_masks_B = B;
+  return PU_OK;
+}
+int pu_set_grad_buckets(pu_ctx* c, int n) {
+  if (!c || n < 0 || n > 16) return PU_ERR_INVALID;
+  DeviceGuard dg(c->device);
+  if (n != c->want_buckets) { c->want_buckets = n; plan_buckets(c); }
+  return PU_OK;
+}
+int pu_grad_buckets(pu_ctx* c, int64_t* lo, int64_t* hi, int max, int* n) {
+  if (!c || !n) return PU_ERR_INVALID;
+  *n = (int)c->buckets.size();
+  for (int k = 0; k < *n && k < max; ++k) { if (lo) lo[k] = c->buckets[k].lo; if (hi) hi[k] = c->buckets[k].hi; }
+  return PU_OK;
+}
+int pu_grad_bucket_wait(pu_ctx* c, int k, void* stream) {
+  if (!c || k < 0 || k >= (int)c->buckets.size()) return PU_ERR_INVALID;
+  DeviceGuard dg(c->device);
+  const auto& q = c->buckets[k];
+  if (!q.rec[0]) FAIL(PU_ERR_STATE, "bucket %d has not been recorded: call pu_elbo_fwd_bwd(with_backward) first", k);
+  for (int i = 0; i < 3; ++i) if (q.rec[i]) CKH(hipStreamWaitEvent((hipStream_t)stream, q.ev[i], 0));
+  return PU_OK;
+}
+int pu_nonfinite_flag(const float* g, int64_t n, float* flag, void* stream) {
+  if (!g || !flag || n < 0) return PU_ERR_INVALID;
+  return launch_nonfinite_flag(g, (long)n, flag, (hipStream_t)stream) == hipSuccess ? PU_OK : PU_ERR_HIP;
+}
+int pu_adamw_step_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2,
+                      float eps, float weight_decay, float* state, const float* skip_flag, void* stream) {
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !state || n < 0) return PU_ERR_INVALID;
+  return launch_adamw_flat_dev(params, grads, exp_avg, exp_avg_sq, (long)n, lr, beta1, beta2, eps, weight_decay, state, skip_flag,
+                               (hipStream_t)stream) == hipSuccess ? PU_OK : PU_ERR_HIP;
+}
+int pu_adamw_prepare(float* state, const float* skip_flag, float lr, float beta1, float beta2, void* stream) {
+  if (!state) return PU_ERR_INVALID;
+  return launch_adamw_flat_dev(nullptr, nullptr, nullptr, nullptr, 0, lr, beta1, beta2, 0.f, 0.f, state, skip_flag, (hipStream_t)stream, 1) == hipSuccess ? PU_OK : PU_ERR_HIP;
+}
+int pu_adamw_apply(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1, float beta2, float eps,
+                   float weight_decay, const float* state, void* stream) {
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !state || n < 0) return PU_ERR_INVALID;
+  return launch_adamw_flat_dev(params, grads, exp_avg, exp_avg_sq, (long)n, lr, beta1, beta2, eps, weight_decay, const_cast<float*>(state), nullptr,
+                               (hipStream_t)stream, 2) == hipSuccess ? PU_OK : PU_ERR_HIP;
+}
+int pu_softplus_transform(float* data, int64_t n, int inverse, float threshold, float cc, void* stream) {
+  if (!data || n < 0) return PU_ERR_INVALID;
+  return launch_softplus_transform(data, (long)n, inverse, threshold, cc, (hipStream_t)stream) == hipSuccess ? PU_OK : PU_ERR_HIP;
+}
+int pu_destandardize(const float* x, const float* base, const float* std_hr, const float* mean_hr, float epsilon, int B, int n, int C, int H, int W,
+                     float* out, void* stream) {
+  if (!x || !std_hr || !out || B < 1 || n < 1 || C < 1 || H < 1 || W < 1) return PU_ERR_INVALID;
+  return launch_destandardize(x, base, std_hr, mean_hr, epsilon, B, n, (long)C * H * W, out, (hipStream_t)stream) == hipSuccess ? PU_OK : PU_ERR_HIP;
 }
 int pu_set_recon_wmse_msssim(pu_ctx* c, float alpha_w, float beta_w, float lam_w, float data_range) {
   if (!c) return PU_ERR_INVALID;

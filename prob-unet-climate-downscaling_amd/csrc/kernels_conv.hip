@@ -9,7 +9,7 @@
 // GEMM orientation: D[row = cout][col = pixel] = W[cout][k] * X[k][pixel], k = (tap, cin-chunk).
 //   v_mfma_f32_32x32x16_{f16,bf16}: lane l holds A[row l&31][k 8(l>>5)..+7], B[k 8(l>>5)..+7][col l&31]
 //   v_mfma_f32_32x32x2_f32        : lane l holds A[row l&31][k l>>5],        B[k l>>5][col l&31]
-//   D: col = l&31, row = (r&3) + 8(r>>2) + 4(l>>5)            (verified on hardware, scratch/mfma_probe.hip)
+//   D: col = l&31, row = (r&3) + 8(r>>2) + 4(l>>5)            (verified on hardware, tools/mfma_probe.hip)
 // LDS tiles are [pixel][channel] / [cout][channel] with the channel (K) axis contiguous, so one ds_read_b128 yields
 // a whole 16-bit fragment; the 3x3 halo tile is staged once per 32-channel chunk and reused by all 9 taps.
 #include <cstdio>
@@ -706,11 +706,11 @@ static hipError_t launch_conv3p_cfg(const ConvArgs& a0, hipStream_t s) {
   constexpr size_t lds = ((size_t)2 * NCH * IH * IW * KCP + (size_t)(TH * TW / (32 * WM)) * 32 * 40 * WM * WN) * sizeof(T);
   static_assert(lds <= 160 * 1024, "conv3p LDS");
   auto kern = conv3p_kernel<T, KS, TH, TW, WM, WN, NCH>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static AttrOnce attr_once;
+  if (!attr_once.cur()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    attr_done = true;
+    attr_once.cur() = true;
   }
   const int ntiles = (a.W / TW) * (a.H / TH) * a.B;
   const int gy = cdiv(a.Cout, BN);
@@ -751,11 +751,11 @@ static hipError_t launch_conv3_cfg(const ConvArgs& a0, hipStream_t s) {
   constexpr size_t lds_ep = (size_t)(TH * TW / (32 * WM)) * 32 * 40 * WM * WN * sizeof(T);      // epilogue staging, wave-private
   constexpr size_t lds = lds_in > lds_ep ? lds_in : lds_ep;
   auto kern = conv3_kernel<T, KS, TH, TW, WM, WN>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static AttrOnce attr_once;
+  if (!attr_once.cur()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    attr_done = true;
+    attr_once.cur() = true;
   }
   dim3 grid((unsigned)((a.W / TW) * (a.H / TH) * a.B), (unsigned)cdiv(a.Cout, BN));
   char tag[128];
@@ -809,11 +809,11 @@ static hipError_t launch_cfg(const ConvArgs& a, hipStream_t s) {
   constexpr int IH = TH + 2 * PADP, IW = TW + 2 * PADP, KCP = KC + MM<T>::PAD, BN = 32 * NTN * WN;
   constexpr size_t lds = (size_t)(IH * IW + TAPS * BN) * KCP * sizeof(T);
   auto kern = conv_igemm_kernel<T, KS, TH, TW, WM, WN, NTN>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static AttrOnce attr_once;
+  if (!attr_once.cur()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    attr_done = true;
+    attr_once.cur() = true;
   }
   dim3 grid((unsigned)((a.W / TW) * (a.H / TH) * a.B), (unsigned)cdiv(a.Cout, BN));
   char tag[128];
@@ -865,7 +865,7 @@ template hipError_t launch_conv<bf16>(const ConvArgs&, hipStream_t);
 // ------------------------------------------------------------------ weight gradient
 // D[row = cout][col = cin] per tap, K = pixels. Operands are read from [pixel][channel] LDS tiles:
 //   16-bit: ds_read_b64_tr_b16 (hardware transposed read: lane i of a 16-lane group receives column i of a
-//           4-row x 16-column block; verified in scratch/mfma_probe.hip), two reads per 8-element fragment.
+//           4-row x 16-column block; verified in tools/mfma_probe.hip), two reads per 8-element fragment.
 //   fp32  : plain ds_read_b32 (the 32x32x2 fragment is one element per lane).
 template <typename T> struct WG;
 template <> struct WG<float> {
@@ -1008,11 +1008,11 @@ static hipError_t launch_wg(const WgradArgs& a, hipStream_t s) {
   constexpr int PADP = KS / 2, BM = TH * TW, IH = TH + 2 * PADP, IW = TW + 2 * PADP;
   constexpr size_t lds = ((size_t)BM * (WG_BCO + WG<T>::DPAD) + (size_t)IH * IW * (WG_BCI + WG<T>::APAD)) * sizeof(T);
   auto kern = conv_wgrad_kernel<T, KS, TH, TW>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static AttrOnce attr_once;
+  if (!attr_once.cur()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    attr_done = true;
+    attr_once.cur() = true;
   }
   const int ntiles = (a.W / TW) * (a.H / TH) * a.B;
   const int gy = cdiv(a.Cout, WG_BCO), gz = cdiv(a.Cin, WG_BCI);

@@ -9,6 +9,33 @@
 
 namespace pu {
 
+// Keep decisions of the VEC consecutive elements starting at the dense NHWC index `base` of a dropout site: bit e set = keep.
+// The hash stream is the product path; an injected mask (uint8 NHWC, 1 = keep: pu_set_drop_masks, parity tests against the
+// oracle's drop_masks= path, networks.py:177) replaces it when present.
+template <int VEC>
+__device__ __forceinline__ uint32_t drop_keep_bits(const GNArgs& f, uint32_t dkey, uint32_t dthr, uint64_t base) {
+  uint32_t bits = 0;
+  if (f.drop_mask) {
+    if (VEC == 8) {
+      const uint2 m = *reinterpret_cast<const uint2*>(f.drop_mask + base);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { bits |= ((m.x >> (8 * e)) & 1u) << e; bits |= ((m.y >> (8 * e)) & 1u) << (e + 4); }
+    } else {
+      const uint32_t m = *reinterpret_cast<const uint32_t*>(f.drop_mask + base);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) bits |= ((m >> (8 * e)) & 1u) << e;
+    }
+    return bits;
+  }
+#pragma unroll
+  for (int e = 0; e < VEC; e += 2) {
+    const uint32_t r = drop_pair(dkey, base + e);
+    bits |= ((r & 0xffffu) < dthr ? 1u : 0u) << e;
+    bits |= ((r >> 16) < dthr ? 1u : 0u) << (e + 1);
+  }
+  return bits;
+}
+
 template <typename T> __device__ __forceinline__ V16 ldv(const T* p) { return *reinterpret_cast<const V16*>(p); }
 template <typename T> __device__ __forceinline__ void stv(T* p, const V16& v) { *reinterpret_cast<V16*>(p) = v; }
 
@@ -240,12 +267,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNArgs a) {
           for (int e = 0; e < VEC; ++e) o[e] = silu_f<sizeof(T) == 4>(A[e] * (v[e] - mu[e]) + Bc[e]);
           if (a.drop_p > 0.f) {
             const uint64_t base = ((uint64_t)(b + a.b0) * OHW + pp) * (uint64_t)C + (uint64_t)cv * VEC;
+            const uint32_t kb = drop_keep_bits<VEC>(a, dkey, dthr, base);
 #pragma unroll
-            for (int e = 0; e < VEC; e += 2) {
-              const uint32_t r = drop_pair(dkey, base + e);
-              o[e] = (r & 0xffffu) < dthr ? o[e] * inv_keep : 0.f;
-              o[e + 1] = (r >> 16) < dthr ? o[e + 1] * inv_keep : 0.f;
-            }
+            for (int e = 0; e < VEC; ++e) o[e] = ((kb >> e) & 1u) ? o[e] * inv_keep : 0.f;
           }
           stv<T>(yp + ((long)b * OHW + pp) * a.y.ld + cv * VEC, pack<T>(o));
         }
@@ -273,12 +297,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNArgs a) {
       for (int e = 0; e < VEC; ++e) o[e] = silu_f<sizeof(T) == 4>(A[e] * (v[e] - mu[e]) + Bc[e]);
       if (RS == RS_NONE && a.drop_p > 0.f) {
         const uint64_t base = ((uint64_t)(b + a.b0) * OHW + p) * (uint64_t)C + (uint64_t)cv * VEC;
+        const uint32_t kb = drop_keep_bits<VEC>(a, dkey, dthr, base);
 #pragma unroll
-        for (int e = 0; e < VEC; e += 2) {
-          const uint32_t r = drop_pair(dkey, base + e);
-          o[e] = (r & 0xffffu) < dthr ? o[e] * inv_keep : 0.f;
-          o[e + 1] = (r >> 16) < dthr ? o[e + 1] * inv_keep : 0.f;
-        }
+        for (int e = 0; e < VEC; ++e) o[e] = ((kb >> e) & 1u) ? o[e] * inv_keep : 0.f;
       }
     }
     stv<T>(yp + ((long)b * OHW + p) * a.y.ld + cv * VEC, pack<T>(o));
@@ -374,12 +395,9 @@ __device__ __forceinline__ void gn_dv(const GNArgs& f, const TV& dy, int b, int 
   if (RS == RS_NONE && f.drop_p > 0.f) {
     const uint32_t dkey = drop_key(f.drop_seed, f.drop_stream), dthr = drop_thr16(keep);
     const uint64_t base = ((uint64_t)(b + f.b0) * HW + p) * (uint64_t)C + (uint64_t)(cv * VEC);
+    const uint32_t kb = drop_keep_bits<VEC>(f, dkey, dthr, base);
 #pragma unroll
-    for (int e = 0; e < VEC; e += 2) {
-      const uint32_t r = drop_pair(dkey, base + e);
-      dh[e] = (r & 0xffffu) < dthr ? dh[e] * inv_keep : 0.f;
-      dh[e + 1] = (r >> 16) < dthr ? dh[e + 1] * inv_keep : 0.f;
-    }
+    for (int e = 0; e < VEC; ++e) dh[e] = ((kb >> e) & 1u) ? dh[e] * inv_keep : 0.f;
   }
 #pragma unroll
   for (int e = 0; e < VEC; ++e) dv[e] = dh[e] * dsilu_f<sizeof(T) == 4>(A[e] * (xv[e] - mu[e]) + Bc[e]);
@@ -431,12 +449,9 @@ __global__ __launch_bounds__(256) void gn_bwd_pass1_kernel(GNBwdArgs a) {
             unpack<T>(rx[u], xv); unpack<T>(rd[u], dh);
             if (f.drop_p > 0.f) {
               const uint64_t base = ((uint64_t)(b + f.b0) * HW + pp) * (uint64_t)C + (uint64_t)(cv * VEC);
+              const uint32_t kb = drop_keep_bits<VEC>(f, dkey, dthr, base);
 #pragma unroll
-              for (int e = 0; e < VEC; e += 2) {
-                const uint32_t r = drop_pair(dkey, base + e);
-                dh[e] = (r & 0xffffu) < dthr ? dh[e] * inv_keep : 0.f;
-                dh[e + 1] = (r >> 16) < dthr ? dh[e + 1] * inv_keep : 0.f;
-              }
+              for (int e = 0; e < VEC; ++e) dh[e] = ((kb >> e) & 1u) ? dh[e] * inv_keep : 0.f;
             }
 #pragma unroll
             for (int e = 0; e < VEC; ++e) {
@@ -571,12 +586,9 @@ __global__ __launch_bounds__(256) void gn_bwd_pass2_kernel(GNBwdArgs a) {
           unpack<T>(rx[u], xv); unpack<T>(rd[u], dh);
           if (f.drop_p > 0.f) {
             const uint64_t base = ((uint64_t)(b + f.b0) * HW + pp) * (uint64_t)C + (uint64_t)(cv * VEC);
+            const uint32_t kb = drop_keep_bits<VEC>(f, dkey, dthr, base);
 #pragma unroll
-            for (int e = 0; e < VEC; e += 2) {
-              const uint32_t r = drop_pair(dkey, base + e);
-              dh[e] = (r & 0xffffu) < dthr ? dh[e] * inv_keep : 0.f;
-              dh[e + 1] = (r >> 16) < dthr ? dh[e + 1] * inv_keep : 0.f;
-            }
+            for (int e = 0; e < VEC; ++e) dh[e] = ((kb >> e) & 1u) ? dh[e] * inv_keep : 0.f;
           }
           if (a.accumulate) unpack<T>(ro[u], o);
           else {
@@ -656,12 +668,9 @@ __global__ __launch_bounds__(256) void gn_small_bwd_kernel(GNBwdArgs a, int CB) 
     unpack<T>(rx, xv); unpack<T>(rd, dh);
     if (f.drop_p > 0.f) {
       const uint64_t base = ((uint64_t)(b + f.b0) * HW + p) * (uint64_t)C + (uint64_t)(c0 + cv * VEC);
+      const uint32_t kb = drop_keep_bits<VEC>(f, dkey, dthr, base);
 #pragma unroll
-      for (int e = 0; e < VEC; e += 2) {
-        const uint32_t r = drop_pair(dkey, base + e);
-        dh[e] = (r & 0xffffu) < dthr ? dh[e] * inv_keep : 0.f;
-        dh[e + 1] = (r >> 16) < dthr ? dh[e + 1] * inv_keep : 0.f;
-      }
+      for (int e = 0; e < VEC; ++e) dh[e] = ((kb >> e) & 1u) ? dh[e] * inv_keep : 0.f;
     }
 #pragma unroll
     for (int e = 0; e < VEC; ++e) dv[e] = dh[e] * dsilu_f<false>(A[e] * (xv[e] - mu[e]) + Bc[e]);
@@ -1262,6 +1271,62 @@ hipError_t launch_adamw_flat(float* p, const float* g, float* m, float* v, long 
                              float step_size, float inv_bc2_sqrt, hipStream_t s, const float* skip_flag) {
   hipLaunchKernelGGL(adamw_flat_kernel, dim3(ew_grid((n + 3) / 4)), dim3(256), 0, s, p, g, m, v, n, lr, beta1, beta2, eps, wd, step_size, inv_bc2_sqrt,
                      skip_flag);
+  return hipGetLastError();
+}
+// Device-side step counter (pu_adamw_step_dev): state = {updates applied so far, lr / bc1, 1 / sqrt(bc2), skip marker}.  One thread
+// advances the counter and derives the bias corrections unless the step is skipped; the update kernel then reads them.
+__global__ void adamw_prepare_kernel(float* __restrict__ state, const float* __restrict__ skip_flag, float lr, float beta1, float beta2) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  if (skip_flag && skip_flag[0] != 0.f) { state[3] = 1.f; return; }
+  const double step = (double)state[0] + 1.0;
+  state[0] = (float)step;
+  state[1] = (float)((double)lr / (1.0 - pow((double)beta1, step)));
+  state[2] = (float)(1.0 / sqrt(1.0 - pow((double)beta2, step)));
+  state[3] = 0.f;
+}
+__global__ void adamw_flat_dev_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v, long n,
+                                      float lr, float beta1, float beta2, float eps, float wd, const float* __restrict__ state) {
+  if (state[3] != 0.f) return;                           // skipped step: parameters, moments and the counter stay as they are
+  const float step_size = state[1], inv_bc2_sqrt = state[2];
+  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long)gridDim.x * blockDim.x * 4) {
+    if (i + 4 <= n) {
+      f32x4 pp = *reinterpret_cast<f32x4*>(p + i), gg = *reinterpret_cast<const f32x4*>(g + i);
+      f32x4 mm = *reinterpret_cast<f32x4*>(m + i), vv = *reinterpret_cast<f32x4*>(v + i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        pp[e] *= 1.f - lr * wd;
+        mm[e] = mm[e] + (gg[e] - mm[e]) * (1.f - beta1);
+        vv[e] = vv[e] * beta2 + gg[e] * gg[e] * (1.f - beta2);
+        pp[e] -= step_size * mm[e] / (sqrtf(vv[e]) * inv_bc2_sqrt + eps);
+      }
+      *reinterpret_cast<f32x4*>(p + i) = pp; *reinterpret_cast<f32x4*>(m + i) = mm; *reinterpret_cast<f32x4*>(v + i) = vv;
+    } else {
+      for (long k = i; k < n; ++k) {
+        float pk = p[k] * (1.f - lr * wd);
+        const float mk = m[k] + (g[k] - m[k]) * (1.f - beta1);
+        const float vk = v[k] * beta2 + g[k] * g[k] * (1.f - beta2);
+        pk -= step_size * mk / (sqrtf(vk) * inv_bc2_sqrt + eps);
+        p[k] = pk; m[k] = mk; v[k] = vk;
+      }
+    }
+  }
+}
+hipError_t launch_adamw_flat_dev(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps, float wd,
+                                 float* state, const float* skip_flag, hipStream_t s, int phases) {
+  if (phases & 1) hipLaunchKernelGGL(adamw_prepare_kernel, dim3(1), dim3(64), 0, s, state, skip_flag, lr, beta1, beta2);
+  if ((phases & 2) && n > 0) hipLaunchKernelGGL(adamw_flat_dev_kernel, dim3(ew_grid((n + 3) / 4)), dim3(256), 0, s, p, g, m, v, n, lr, beta1, beta2, eps, wd, state);
+  return hipGetLastError();
+}
+// injected dropout masks: fp32 NCHW [B,C,HW] (non-zero = keep) -> uint8 NHWC [B,HW,C]
+__global__ void mask_to_nhwc_u8_kernel(const float* __restrict__ src, uint8_t* __restrict__ dst, int B, int C, long HW) {
+  const long total = (long)B * C * HW;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C); const long p = (i / C) % HW; const long b = i / ((long)C * HW);
+    dst[i] = src[(b * C + c) * HW + p] != 0.f ? 1 : 0;
+  }
+}
+hipError_t launch_mask_to_nhwc_u8(const float* src, uint8_t* dst, int B, int C, long HW, hipStream_t s) {
+  hipLaunchKernelGGL(mask_to_nhwc_u8_kernel, dim3(ew_grid((long)B * C * HW)), dim3(256), 0, s, src, dst, B, C, HW);
   return hipGetLastError();
 }
 // flag[0] = 1 if any of the n floats is inf / NaN (the flag must have been zeroed before)

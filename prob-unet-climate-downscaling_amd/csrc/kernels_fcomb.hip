@@ -639,11 +639,11 @@ hipError_t launch_fcomb_bwd(const FcombBwdArgs& a, hipStream_t s) {
   dim3 grid((unsigned)min((long)16, nchunks), f.B);
   if (f.Cout > f.F) return hipErrorInvalidValue;
   const size_t lds = (size_t)2 * 256 * (f.F + 1) * sizeof(float);
-  static bool attr_done = false;
-  if (!attr_done) {
+  static AttrOnce attr_once;
+  if (!attr_once.cur()) {
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(fcomb_bwd_kernel<T, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 256 * 33 * 4);
     if (e != hipSuccess) return e;
-    attr_done = true;
+    attr_once.cur() = true;
   }
   if (f.F == 32 && sizeof(T) == 2) {
     if constexpr (sizeof(T) == 2) {

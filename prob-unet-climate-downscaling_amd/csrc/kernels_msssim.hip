@@ -367,12 +367,12 @@ hipError_t launch_wmse_msssim(const MsssimArgs& a, hipStream_t s) {
   }
   hipLaunchKernelGGL(ms_combine_kernel, dim3(1), dim3(256), 0, s, part0, d, NC, a.M, a.C, a.lam_w, a.gscale, a.dpred ? gco : nullptr, a.scalars);
   if (a.dpred) {
-    static bool attr_done = false;
-    if (!attr_done) {
+    static AttrOnce attr_once;
+    if (!attr_once.cur()) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ms_level_bwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_LDS);
       if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(ms_level_bwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_LDS);
       if (e != hipSuccess) return e;
-      attr_done = true;
+      attr_once.cur() = true;
     }
     for (int l = NLV - 1; l >= 0; --l) {
       const dim3 grid(cdiv(d.W[l], T), cdiv(d.H[l], T), NC);
@@ -453,6 +453,42 @@ __global__ void lr_stats_kernel(const float* __restrict__ hr, int N, int C, int 
 hipError_t launch_lr_stats(const float* hr, int N, int C, int H, int W, int k, float* mean_lr, float* std_lr, float* mean_hr, float* std_hr, hipStream_t s) {
   const long cells = (long)C * (H / k) * (W / k);
   hipLaunchKernelGGL(lr_stats_kernel, dim3((unsigned)cdiv(cells, 64)), dim3(64), 0, s, hr, N, C, H, W, k, mean_lr, std_lr, mean_hr, std_hr);
+  return hipGetLastError();
+}
+
+// softplus / softplus_inv of climex_utils.py:36-46, in place like the reference:
+//   softplus    : v > thr ? v : log(exp(v) + 1) - c          (inverse of the load-time pre-transform)
+//   softplus_inv: v > thr ? v : log(exp(v + c) - 1)          (applied to precipitation and tasmax - tasmin when transfo=True, :141-143)
+__global__ void softplus_transform_kernel(float* __restrict__ d, long n, int inverse, float thr, float c) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float v = d[i];
+    if (!(v > thr)) d[i] = inverse ? logf(expf(v + c) - 1.f) : logf(expf(v) + 1.f) - c;
+  }
+}
+hipError_t launch_softplus_transform(float* d, long n, int inverse, float thr, float c, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(softplus_transform_kernel, dim3((unsigned)(cdiv(n, 256) > 8192 ? 8192 : cdiv(n, 256))), dim3(256), 0, s, d, n, inverse, thr, c);
+  return hipGetLastError();
+}
+// invstand_residual / residual_to_hr (climex_utils.py:270-285) on tensors that already exist:
+//   out[b,s,c,p] = (base ? base[b,c,p] : 0) + x[b,s,c,p] * (std[c,p] + eps) + (mean ? mean[c,p] : 0)
+__global__ void destandardize_kernel(const float* __restrict__ x, const float* __restrict__ base, const float* __restrict__ stdv,
+                                     const float* __restrict__ mean, float eps, int B, int n, long CHW, float* __restrict__ out) {
+  const long total = (long)B * n * CHW;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long q = i % CHW; const long b = i / (CHW * n);
+    float v = x[i] * (stdv[q] + eps);
+    if (mean) v += mean[q];
+    if (base) v = base[b * CHW + q] + v;
+    out[i] = v;
+  }
+}
+hipError_t launch_destandardize(const float* x, const float* base, const float* stdv, const float* mean, float eps, int B, int n, long CHW,
+                                float* out, hipStream_t s) {
+  const long total = (long)B * n * CHW;
+  if (total <= 0) return hipSuccess;
+  hipLaunchKernelGGL(destandardize_kernel, dim3((unsigned)(cdiv(total, 256) > 8192 ? 8192 : cdiv(total, 256))), dim3(256), 0, s, x, base, stdv, mean,
+                     eps, B, n, CHW, out);
   return hipGetLastError();
 }
 

@@ -267,11 +267,11 @@ static hipError_t launch_wg16(const WgradArgs& a, hipStream_t s) {
   constexpr int PADP = KS / 2, BM = TH * TW, NPH = (TH + 2 * PADP) * (TW + 2 * PADP), TAPS = KS * KS;
   constexpr size_t lds = (size_t)2 * (2 * BM + (BCI / 32) * NPH) * 32 * 2;
   auto kern = conv_wgrad16_kernel<T, KS, TH, TW, BCI, NW>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static AttrOnce attr_once;
+  if (!attr_once.cur()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    attr_done = true;
+    attr_once.cur() = true;
   }
   const int ntiles = (a.W / TW) * (a.H / TH) * a.B;
   const int gy = cdiv(a.Cout, WBCO), gz = cdiv(a.Cin, BCI);

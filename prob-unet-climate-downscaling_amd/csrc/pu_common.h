@@ -112,6 +112,20 @@ __device__ __forceinline__ uint32_t drop_pair(uint32_t key, uint64_t idx) {
   return hash32((uint32_t)(idx >> 1) * 0x9E3779B1u + key + (uint32_t)(idx >> 33));
 }
 
+// hipFuncSetAttribute is per device: each launcher remembers which devices it has configured
+struct AttrOnce {
+  bool done[32] = {};
+  bool& cur() { int d = 0; (void)hipGetDevice(&d); return done[d & 31]; }
+};
+// RAII: make `dev` current for the duration of an entry point and restore the caller's device afterwards
+struct DeviceGuard {
+  int prev = -1; bool switched = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+  }
+  ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+};
+
 inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 inline int rup(int a, int b) { return (a + b - 1) / b * b; }
 

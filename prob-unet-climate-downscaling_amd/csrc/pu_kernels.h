@@ -61,6 +61,7 @@ struct GNArgs {
   const float* scale; const float* shift;         // fp32 [C] each or null (adaptive: y = silu(gn*(1+scale)+shift))
   int resample;
   float drop_p; uint64_t drop_seed; uint32_t drop_stream;   // drop_p == 0 -> no dropout
+  const uint8_t* drop_mask;   // optional injected keep mask, dense NHWC uint8 [B,H,W,C] of this site (null: counter hash)
   // workspaces (fp32): part [B][nchunk][C][2], stat [B][G][2] (mean, rstd), coef [B][C][4] (A, Bp, mean, rstd; 16-byte aligned)
   float* part; float* stat; float* coef; int nchunk;
   // producer-fused statistics (see ConvArgs::stat_out): channels [0, pc0) from ps0 (ns0 slots per image), the rest from ps1;
@@ -160,6 +161,9 @@ hipError_t launch_fill(float* p, float v, long n, hipStream_t);
 hipError_t launch_adamw_flat(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps, float wd,
                              float step_size, float inv_bc2_sqrt, hipStream_t, const float* skip_flag = nullptr);
 hipError_t launch_nonfinite_flag(const float* g, long n, float* flag, hipStream_t);
+hipError_t launch_adamw_flat_dev(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps, float wd,
+                                 float* state, const float* skip_flag, hipStream_t, int phases = 3);   // 1 = advance the counter, 2 = update
+hipError_t launch_mask_to_nhwc_u8(const float* src, uint8_t* dst, int B, int C, long HW, hipStream_t);
 
 // ---------------------------------------------------------------- optional per-kernel-class profiling (bench roofline)
 // When enabled, every MFMA conv launch is bracketed by HIP events on its own stream; prof_collect() sums elapsed time,
@@ -187,5 +191,8 @@ hipError_t launch_wmse_msssim(const MsssimArgs&, hipStream_t);
 hipError_t launch_lrinterp_residuals(const float* hr, int B, int C, int H, int W, int k, const float* mean, const float* stdv, float eps,
                                      float* inputs, float* targets, float* lrinterp, float* lr, hipStream_t s);
 hipError_t launch_lr_stats(const float* hr, int N, int C, int H, int W, int k, float* mean_lr, float* std_lr, float* mean_hr, float* std_hr, hipStream_t s);
+hipError_t launch_softplus_transform(float* d, long n, int inverse, float thr, float c, hipStream_t s);
+hipError_t launch_destandardize(const float* x, const float* base, const float* stdv, const float* mean, float eps, int B, int n, long CHW,
+                                float* out, hipStream_t s);
 
 }  // namespace pu

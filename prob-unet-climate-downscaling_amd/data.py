@@ -56,13 +56,57 @@ def lrinterp_to_residuals(hr: torch.Tensor, lowres_scale: int, mean_hr: torch.Te
     return out
 
 
-class ClimExTransform:
-    """Device-side stand-in for the parts of ClimExDataset the training / sampling loops touch (type
-    "lrinterp_to_residuals"): statistics, the batched item transform, `invstand_residual` and `residual_to_hr`."""
+def softplus(data: torch.Tensor, threshold: float = 20.0, c: float = 1e-7) -> torch.Tensor:
+    """climex_utils.softplus (:41-45), IN PLACE like the reference: v > threshold ? v : log(exp(v) + 1) - c."""
+    if not data.is_cuda or data.dtype != torch.float32 or not data.is_contiguous():
+        raise L.ProbUNetLibraryError("softplus works in place on a contiguous fp32 device tensor (no CPU fallback)")
+    L.check(L.lib().pu_softplus_transform(L.ptr(data), data.numel(), 0, float(threshold), float(c), L.current_stream(data.device)), None,
+            "pu_softplus_transform")
+    return data
 
-    def __init__(self, lowres_scale: int = 4, epsilon: float = 1e-10):
+
+def softplus_inv(data: torch.Tensor, threshold: float = 20.0, c: float = 1e-7) -> torch.Tensor:
+    """climex_utils.softplus_inv (:36-40), IN PLACE: v > threshold ? v : log(exp(v + c) - 1) - the load-time pre-transform of
+    precipitation and of tasmax - tasmin (climex_utils.py:141-143, `transfo=True`)."""
+    if not data.is_cuda or data.dtype != torch.float32 or not data.is_contiguous():
+        raise L.ProbUNetLibraryError("softplus_inv works in place on a contiguous fp32 device tensor (no CPU fallback)")
+    L.check(L.lib().pu_softplus_transform(L.ptr(data), data.numel(), 1, float(threshold), float(c), L.current_stream(data.device)), None,
+            "pu_softplus_transform")
+    return data
+
+
+def destandardize(x: torch.Tensor, std_hr: torch.Tensor, base: Optional[torch.Tensor] = None, mean_hr: Optional[torch.Tensor] = None,
+                  epsilon: float = 1e-10) -> torch.Tensor:
+    """invstand_residual / residual_to_hr (climex_utils.py:270-285) in one pass:
+    out = (base if given) + x * (std_hr + epsilon) + (mean_hr if given).  x [B, C, H, W] or [B, n, C, H, W]; base [B, C, H, W]."""
+    x = _dev32(x)
+    five = x.dim() == 5
+    xx = x if five else x.unsqueeze(1)
+    B, n, C_, H, W = xx.shape
+    std_hr = _dev32(std_hr)
+    if tuple(std_hr.shape) != (C_, H, W):
+        raise ValueError("std_hr must be [C, H, W]")
+    base = _dev32(base) if base is not None else None
+    mean_hr = _dev32(mean_hr) if mean_hr is not None else None
+    if base is not None and tuple(base.shape) != (B, C_, H, W):
+        raise ValueError("base (lrinterp) must be [B, C, H, W]")
+    out = torch.empty_like(xx)
+    L.check(L.lib().pu_destandardize(L.ptr(xx.contiguous()), L.ptr(base), L.ptr(std_hr), L.ptr(mean_hr), float(epsilon), B, n, C_, H, W,
+                                     L.ptr(out), L.current_stream(x.device)), None, "pu_destandardize")
+    return out if five else out[:, 0]
+
+
+class ClimExTransform:
+    """Device-side stand-in for the parts of ClimExDataset the training / sampling loops touch: statistics, the batched item
+    transform of the "lrinterp_to_residuals" pipeline (kind="lrinterp_to_hr": targets are the standardised hr itself,
+    climex_utils.py:228-250), `invstand_residual` and `residual_to_hr`."""
+
+    def __init__(self, lowres_scale: int = 4, epsilon: float = 1e-10, kind: str = "lrinterp_to_residuals"):
+        if kind not in ("lrinterp_to_residuals", "lrinterp_to_hr"):
+            raise ValueError("kind must be 'lrinterp_to_residuals' or 'lrinterp_to_hr'")
         self.lowres_scale = int(lowres_scale)
         self.epsilon = float(epsilon)
+        self.kind = kind
         self.lrstats = None
 
     def fit(self, hr: torch.Tensor):
@@ -73,14 +117,16 @@ class ClimExTransform:
         if self.lrstats is None:
             raise RuntimeError("call fit(hr) first (the reference computes the statistics lazily from its whole hr array)")
         out = lrinterp_to_residuals(hr, self.lowres_scale, self.lrstats[1][0], self.lrstats[1][1], self.epsilon)
+        if self.kind == "lrinterp_to_hr":
+            out["targets"] = out["targets"] + out["inputs"]           # hr_stand = residual + lrinterp_stand (climex_utils.py:241-242)
         if timestamps is not None:
             out["timestamps"] = timestamps
         return out
 
     def invstand_residual(self, standardized_residual: torch.Tensor) -> torch.Tensor:        # climex_utils.py:270-274
-        return standardized_residual * (self.lrstats[1][1] + self.epsilon)
+        mean = self.lrstats[1][0] if self.kind == "lrinterp_to_hr" else None
+        return destandardize(standardized_residual, self.lrstats[1][1], None, mean, self.epsilon)
 
     def residual_to_hr(self, residual: torch.Tensor, lrinterp: torch.Tensor) -> torch.Tensor:  # climex_utils.py:277-278
-        if residual.dim() == 5:
-            return lrinterp.unsqueeze(1) + self.invstand_residual(residual)
-        return lrinterp + self.invstand_residual(residual)
+        mean = self.lrstats[1][0] if self.kind == "lrinterp_to_hr" else None
+        return destandardize(residual, self.lrstats[1][1], lrinterp, mean, self.epsilon)

@@ -140,10 +140,12 @@ class _DeliverGrads(torch.autograd.Function):
     @staticmethod
     def forward(ctx, value, anchor, owner, lo, hi):
         ctx.owner, ctx.lo, ctx.hi = owner, lo, hi
+        ctx.gen = owner._gen["grads"]
         return value.view_as(value)
 
     @staticmethod
     def backward(ctx, g):
+        ctx.owner._check_fresh("grads", ctx.gen, "elbo()")
         ctx.owner._deliver(g, ctx.lo, ctx.hi)
         return None, None, None, None, None
 
@@ -152,14 +154,21 @@ class _UNetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, anchor, owner):
         ctx.owner = owner
-        return owner._unet_fwd(x)
+        out = owner._unet_fwd(x)
+        ctx.gen, ctx.xin = owner._gen["unet"], owner._xin_token
+        return out
 
     @staticmethod
     def backward(ctx, dfeat):
         o = ctx.owner
+        o._check_fresh("unet", ctx.gen, "model.unet(x)")
+        if o._xin_token != ctx.xin:
+            raise L.ProbUNetLibraryError("stale engine state: the input planes saved by model.unet(x) were overwritten by a later "
+                                         "model.prior(x') call with a different x before backward() (one forward in flight per engine)")
+        o._gen["grads"] += 1
         lo, hi = o._ranges["unet"]
         o._engine_grads[lo:hi].zero_()
-        L.check(L.lib().pu_unet_bwd(o._ctx, L.ptr(dfeat.contiguous().float()), L.current_stream()), o._ctx, "pu_unet_bwd")
+        L.check(L.lib().pu_unet_bwd(o._ctx, L.ptr(dfeat.contiguous().float()), o._stream()), o._ctx, "pu_unet_bwd")
         o._deliver(None, lo, hi)
         return None, None, None
 
@@ -169,16 +178,23 @@ class _GaussFn(torch.autograd.Function):
     def forward(ctx, x, target, anchor, owner, which):
         ctx.owner, ctx.which = owner, which
         mu, ls = owner._gauss_fwd(which, x, target)
+        ctx.name = "posterior" if which == L.PU_POSTERIOR else "prior"
+        ctx.gen, ctx.xin = owner._gen[ctx.name], owner._xin_token
         return mu, ls
 
     @staticmethod
     def backward(ctx, dmu, dls):
         o = ctx.owner
-        lo, hi = o._ranges["posterior" if ctx.which == L.PU_POSTERIOR else "prior"]
+        o._check_fresh(ctx.name, ctx.gen, f"model.{ctx.name}(...)")
+        if ctx.which == L.PU_PRIOR and o._xin_token != ctx.xin:
+            raise L.ProbUNetLibraryError("stale engine state: the input planes saved by model.prior(x) were overwritten by a later "
+                                         "model.unet(x') call with a different x before backward() (one forward in flight per engine)")
+        o._gen["grads"] += 1
+        lo, hi = o._ranges[ctx.name]
         o._engine_grads[lo:hi].zero_()
         dmu = torch.zeros_like(o._last_mu[ctx.which]) if dmu is None else dmu.contiguous().float()
         dls = torch.zeros_like(dmu) if dls is None else dls.contiguous().float()
-        L.check(L.lib().pu_gauss_bwd(o._ctx, ctx.which, L.ptr(dmu), L.ptr(dls), L.current_stream()), o._ctx, "pu_gauss_bwd")
+        L.check(L.lib().pu_gauss_bwd(o._ctx, ctx.which, L.ptr(dmu), L.ptr(dls), o._stream()), o._ctx, "pu_gauss_bwd")
         o._deliver(None, lo, hi)
         return None, None, None, None, None
 
@@ -188,17 +204,21 @@ class _FcombFn(torch.autograd.Function):
     def forward(ctx, feat, z, anchor, owner):
         ctx.owner = owner
         ctx.shape = tuple(feat.shape)
-        return owner._fcomb_fwd(feat, z)
+        out = owner._fcomb_fwd(feat, z)
+        ctx.gen = owner._gen["fcomb"]
+        return out
 
     @staticmethod
     def backward(ctx, dout):
         o = ctx.owner
+        o._check_fresh("fcomb", ctx.gen, "model.fcomb(...)")
+        o._gen["grads"] += 1
         lo, hi = o._ranges["fcomb"]
         o._engine_grads[lo:hi].zero_()
         B = dout.shape[0]
         dfeat = torch.empty(ctx.shape, device=dout.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
         dz = torch.empty(B, o.latent_dim, device=dout.device, dtype=torch.float32)
-        L.check(L.lib().pu_fcomb_bwd(o._ctx, L.ptr(dout.contiguous().float()), L.ptr(dfeat), L.ptr(dz), L.current_stream()),
+        L.check(L.lib().pu_fcomb_bwd(o._ctx, L.ptr(dout.contiguous().float()), L.ptr(dfeat), L.ptr(dz), o._stream()),
                 o._ctx, "pu_fcomb_bwd")
         o._deliver(None, lo, hi)
         return dfeat, dz, None, None
@@ -284,6 +304,14 @@ class ProbabilisticUNet(nn.Module):
         self._dp_group = None
         self._dp_world = 1
         self.dp_bucket_elems = 0
+        self.dp_overlap_buckets = 4       # U-Net gradient buckets all-reduced under the rest of the backward (0: one all-reduce in backward())
+        self._dp_works = None             # in-flight bucket collectives of the last fused elbo()
+        self._comm_stream = None
+        self.use_sample_graph = True      # cfg5: pu_sample / pu_sample_hr launch sequences are captured in a hipGraph and replayed
+        # one forward in flight per engine: every entry that overwrites saved engine state bumps its generation; backward checks it
+        self._gen = {"unet": 0, "prior": 0, "posterior": 0, "fcomb": 0, "grads": 0}
+        self._xin_token = None            # identity of the tensor last converted into the engine's shared input planes
+        self._drop_masks = None
 
         # ---- parameter tree from the engine's own table (names/shapes/order of the reference state_dict)
         table = self._query_table()
@@ -338,7 +366,7 @@ class ProbabilisticUNet(nn.Module):
     def _latent_dist(self, which, B):
         dev = self._owner_device()
         mu = torch.empty(B, self.latent_dim, device=dev, dtype=torch.float32); sg = torch.empty_like(mu)
-        L.check(L.lib().pu_last_latent(self._ctx, which, L.ptr(mu), L.ptr(sg), B, L.current_stream()), self._ctx, "pu_last_latent")
+        L.check(L.lib().pu_last_latent(self._ctx, which, L.ptr(mu), L.ptr(sg), B, self._stream()), self._ctx, "pu_last_latent")
         return Independent(Normal(loc=mu, scale=sg), 1)
 
     @property
@@ -382,6 +410,52 @@ class ProbabilisticUNet(nn.Module):
     def _owner_device(self):
         return next(self.parameters()).device
 
+    def _stream(self):
+        return L.current_stream(self._owner_device())
+
+    def _check_fresh(self, kind, gen, what):
+        if self._gen[kind] != gen:
+            raise L.ProbUNetLibraryError(
+                f"stale engine state: {what} was followed by another call that overwrote the engine's saved "
+                f"{'gradients' if kind == 'grads' else 'activations'} before backward().  The engine keeps ONE forward in flight "
+                "(static activation plan): call backward() before the next forward of the same sub-module / elbo(), or run the "
+                "second forward under torch.no_grad().")
+
+    def _touch_xin(self, x):
+        self._xin_token = (x.data_ptr(), x._version, tuple(x.shape))
+
+    def set_drop_masks(self, masks):
+        """Inject dropout keep-masks (parity runs against a reference that draws them from torch's RNG, networks.py:177).
+        masks: {block prefix (e.g. "unet.enc.128x128_block0"): 0/1 tensor [B, C, H, W]} for EVERY UNetBlock, or None to return
+        to the engine's counter-hash stream.  They apply to train-mode calls with that batch size until cleared."""
+        self._drop_masks = masks
+        if self._ctx is not None:
+            self._push_drop_masks()
+
+    def _push_drop_masks(self):
+        masks = self._drop_masks
+        lib = L.lib()
+        if masks is None:
+            L.check(lib.pu_set_drop_masks(self._ctx, None, 0, self._stream()), self._ctx, "pu_set_drop_masks")
+            return
+        n = lib.pu_drop_site_count(self._ctx)
+        parts, B = [], None
+        for i in range(n):
+            name = C.create_string_buffer(96); c_, h_, w_ = C.c_int(), C.c_int(), C.c_int()
+            L.check(lib.pu_drop_site(self._ctx, i, name, C.byref(c_), C.byref(h_), C.byref(w_)), self._ctx, "pu_drop_site")
+            key = name.value.decode()
+            if key not in masks:
+                raise ValueError(f"set_drop_masks: no mask for dropout site {key}")
+            m = masks[key]
+            if B is None:
+                B = int(m.shape[0])
+            if tuple(m.shape) != (B, c_.value, h_.value, w_.value):
+                raise ValueError(f"set_drop_masks: mask of {key} must be [{B}, {c_.value}, {h_.value}, {w_.value}], got {tuple(m.shape)}")
+            parts.append(m.to(self._owner_device(), torch.float32).reshape(-1))
+        flat = torch.cat(parts).contiguous()
+        L.check(lib.pu_set_drop_masks(self._ctx, L.ptr(flat), B, self._stream()), self._ctx, "pu_set_drop_masks")
+        self._mask_keepalive = flat
+
     def _ensure(self, H, W, B, M):
         dev = self._owner_device()
         if dev.type != "cuda":
@@ -399,11 +473,19 @@ class ProbabilisticUNet(nn.Module):
         L.check(L.lib().pu_create(C.byref(cfg), dev.index or 0, C.byref(ctx)), None, "pu_create")
         self._ctx, self._ctx_key = ctx, key
         self._packed_once = False
+        for k in self._gen:                      # a new plan: every saved activation / gradient of the old one is gone
+            self._gen[k] += 1
+        self._xin_token = None
         n = L.lib().pu_param_count(ctx)
         if n != self._nparams:
             raise L.ProbUNetLibraryError(f"parameter count mismatch: engine {n} vs host {self._nparams}")
         self._flatten(dev)
         L.check(L.lib().pu_bind_params(ctx, L.ptr(self._flat), L.ptr(self._engine_grads)), ctx, "pu_bind_params")
+        L.lib().pu_set_sample_graph(ctx, 1 if self.use_sample_graph else 0)
+        if self._dp_world > 1 and self.dp_overlap_buckets > 0:
+            L.lib().pu_set_grad_buckets(ctx, int(self.dp_overlap_buckets))
+        if self._drop_masks is not None:
+            self._push_drop_masks()
 
     def _release(self):
         if self._ctx is not None:
@@ -471,12 +553,14 @@ class ProbabilisticUNet(nn.Module):
         if self._dp_world > 1:
             from .dp import allreduce_mean_
             # the 1 / world of the mean rides on the copy below when there is one (saves a pass over the 300 MB buffer)
-            allreduce_mean_(eg, self._dp_group, self.dp_bucket_elems, average=not fresh)
-            sc = getattr(self, "_last_scalars", None)
-            if self.compute_dtype in ("f16", "fp16", "float16") and sc is not None and lo == 0 and hi == self._nparams:
-                # an overflow on ANY rank poisons the averaged gradient of EVERY rank: share the flag so that all ranks skip together
-                import torch.distributed as dist
-                dist.all_reduce(sc[L.PU_S_NONFINITE:L.PU_S_NONFINITE + 1], op=dist.ReduceOp.MAX, group=self._dp_group)
+            if self._dp_works is not None and lo == 0 and hi == self._nparams:
+                self._finish_dp_works()                   # bucketed collectives issued by elbo(): only wait for them here
+                if not fresh:
+                    eg.mul_(1.0 / self._dp_world)
+            else:
+                allreduce_mean_(eg, self._dp_group, self.dp_bucket_elems, average=not fresh)
+            # an overflow on ANY rank makes the SUM non-finite on EVERY rank (inf + x = inf, inf - inf = NaN): the optimizer derives
+            # its skip flag from the averaged buffer (FlatAdamW.step), so all ranks skip together without another collective
             if fresh:
                 g = (g.reshape(()) if g is not None else torch.ones((), device=eg.device)) * (1.0 / self._dp_world)
         if fresh:
@@ -495,6 +579,41 @@ class ProbabilisticUNet(nn.Module):
                     p.grad = ge.clone()
                 else:
                     p.grad.add_(ge)
+
+    def _start_bucket_allreduce(self):
+        """Issue one all-reduce (SUM) per gradient bucket of the fused backward on a side stream that waits for the bucket's
+        completion events (pu_grad_bucket_wait): the collectives run while the GPU is still working through the rest of the
+        backward.  Called right after pu_elbo_fwd_bwd returned (everything is enqueued by then); `_deliver` waits for them."""
+        import torch.distributed as dist
+        lib = L.lib()
+        n = C.c_int(0)
+        lo = (C.c_int64 * 32)(); hi = (C.c_int64 * 32)()
+        L.check(lib.pu_grad_buckets(self._ctx, lo, hi, 32, C.byref(n)), self._ctx, "pu_grad_buckets")
+        if n.value == 0:
+            return
+        dev = self._owner_device()
+        if self._comm_stream is None or self._comm_stream.device != dev:
+            self._comm_stream = torch.cuda.Stream(device=dev)
+        cs = self._comm_stream
+        works = []
+        with torch.cuda.stream(cs):
+            for k in range(n.value):
+                L.check(lib.pu_grad_bucket_wait(self._ctx, k, C.c_void_p(cs.cuda_stream)), self._ctx, "pu_grad_bucket_wait")
+                works.append(dist.all_reduce(self._engine_grads[lo[k]:hi[k]], op=dist.ReduceOp.SUM, group=self._dp_group, async_op=True))
+        self._dp_works = works
+
+    def _dp_bucket_ranges(self):
+        n = C.c_int(0); lo = (C.c_int64 * 32)(); hi = (C.c_int64 * 32)()
+        if self._ctx is None:
+            return []
+        L.check(L.lib().pu_grad_buckets(self._ctx, lo, hi, 32, C.byref(n)), self._ctx, "pu_grad_buckets")
+        return [(int(lo[k]), int(hi[k])) for k in range(n.value)]
+
+    def _finish_dp_works(self):
+        if self._dp_works is not None:
+            for w in self._dp_works:
+                w.wait()                                  # the current stream waits for the collective's stream (no host sync with RCCL)
+            self._dp_works = None
 
     def _grad_views(self, lo, hi):
         key = ("gv", lo, hi, self._flat_grad.data_ptr())
@@ -538,10 +657,19 @@ class ProbabilisticUNet(nn.Module):
         self._dp_group = process_group
         self._dp_world = dist.get_world_size(process_group)
         if self._dp_world > 1:
-            for p in self.parameters():
-                dist.broadcast(p.data, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0, group=process_group)
+            src = dist.get_global_rank(process_group, 0) if process_group is not None else 0
+            dev = self._owner_device()
+            if dev.type == "cuda":
+                if self._flat is None:
+                    self._flatten(dev)                    # every nn.Parameter becomes a view of the flat buffer: ONE broadcast of 303 MB
+                dist.broadcast(self._flat, src=src, group=process_group)
+            else:                                         # parameters still on the host (model.to(device) comes later): per tensor
+                for p in self.parameters():
+                    dist.broadcast(p.data, src=src, group=process_group)
             if self._ctx is not None:
                 self._params_dirty()
+                if self.dp_overlap_buckets > 0:
+                    L.lib().pu_set_grad_buckets(self._ctx, int(self.dp_overlap_buckets))
         return self
 
     # ------------------------------------------------------------------ raw engine calls
@@ -559,7 +687,8 @@ class ProbabilisticUNet(nn.Module):
         self._params_dirty(force=False)
         feat = torch.empty(B, self.num_filters[0], H, W, device=x.device, dtype=torch.float32)
         train = 1 if (self.training and self.dropout > 0) else 0
-        L.check(L.lib().pu_unet_fwd(self._ctx, L.ptr(x), L.ptr(feat), B, train, self._next_seed(), L.current_stream()), self._ctx, "pu_unet_fwd")
+        self._gen["unet"] += 1; self._touch_xin(x)
+        L.check(L.lib().pu_unet_fwd(self._ctx, L.ptr(x), L.ptr(feat), B, train, self._next_seed(), self._stream()), self._ctx, "pu_unet_fwd")
         return feat
 
     def _gauss_fwd(self, which, x, target):
@@ -576,8 +705,11 @@ class ProbabilisticUNet(nn.Module):
                     raise ValueError(f"expected {self.num_classes} target planes, got {target.shape[1]}")
         mu = torch.empty(B, self.latent_dim, device=x.device, dtype=torch.float32)
         ls = torch.empty_like(mu)
+        self._gen["posterior" if which == L.PU_POSTERIOR else "prior"] += 1
+        if which == L.PU_PRIOR:
+            self._touch_xin(x)
         L.check(L.lib().pu_gauss_fwd(self._ctx, which, L.ptr(x), L.ptr(target) if which == L.PU_POSTERIOR else None, L.ptr(mu), L.ptr(ls), B,
-                                     L.current_stream()), self._ctx, "pu_gauss_fwd")
+                                     self._stream()), self._ctx, "pu_gauss_fwd")
         self._last_mu[which] = mu
         return mu, ls
 
@@ -595,7 +727,8 @@ class ProbabilisticUNet(nn.Module):
         self._ensure(H, W, B, 1)
         self._params_dirty(force=False)
         out = torch.empty(B, self.num_classes, H, W, device=feat.device, dtype=torch.float32)
-        L.check(L.lib().pu_fcomb_fwd(self._ctx, L.ptr(src), bstride, L.ptr(z.contiguous().float()), L.ptr(out), B, L.current_stream()),
+        self._gen["fcomb"] += 1
+        L.check(L.lib().pu_fcomb_fwd(self._ctx, L.ptr(src), bstride, L.ptr(z.contiguous().float()), L.ptr(out), B, self._stream()),
                 self._ctx, "pu_fcomb_fwd")
         return out
 
@@ -674,12 +807,20 @@ class ProbabilisticUNet(nn.Module):
         if msssim:
             L.check(L.lib().pu_set_recon_wmse_msssim(self._ctx, float(alpha_w), float(beta_w), float(lam_w),
                                                      -1.0 if data_range is None else float(data_range)), self._ctx, "pu_set_recon_wmse_msssim")
+        for k in ("unet", "prior", "posterior"):          # the fused call overwrites every saved activation (and, with backward, the gradients)
+            self._gen[k] += 1
+        self._touch_xin(x)
+        if with_bwd:
+            self._gen["grads"] += 1
+            self._finish_dp_works()                       # a previous elbo()'s collectives still own the gradient buffer
         L.check(L.lib().pu_elbo_fwd_bwd(self._ctx, L.ptr(x), L.ptr(target), L.ptr(eps), B, Mx, kind,
                                         float(self.beta_0), float(self.beta_1), float(self.beta_2), float(alpha), train,
-                                        self._next_seed(), with_bwd, L.ptr(scal), L.ptr(klv), L.ptr(kl2v), L.current_stream()),
+                                        self._next_seed(), with_bwd, L.ptr(scal), L.ptr(klv), L.ptr(kl2v), self._stream()),
                 self._ctx, "pu_elbo_fwd_bwd")
         total = scal[L.PU_S_TOTAL]
         if with_bwd:
+            if self._dp_world > 1 and self.dp_overlap_buckets > 0:
+                self._start_bucket_allreduce()            # enqueued now, runs under the rest of the backward on the GPU
             total = _DeliverGrads.apply(total, self._anchor_t(), self, 0, self._nparams)
         recon = scal[L.PU_S_RECON]
         self._last_scalars = scal
@@ -716,7 +857,8 @@ class ProbabilisticUNet(nn.Module):
         eps = eps.contiguous().float()
         out = torch.empty(B, n, self.num_classes, H, W, device=x.device, dtype=torch.float32)
         mu = torch.empty(B, self.latent_dim, device=x.device, dtype=torch.float32); sg = torch.empty_like(mu)
-        L.check(L.lib().pu_sample(self._ctx, L.ptr(x), L.ptr(target), L.ptr(eps), B, n, L.ptr(out), L.ptr(mu), L.ptr(sg), L.current_stream()),
+        self._gen["unet"] += 1; self._gen["posterior" if target is not None else "prior"] += 1; self._touch_xin(x)
+        L.check(L.lib().pu_sample(self._ctx, L.ptr(x), L.ptr(target), L.ptr(eps), B, n, L.ptr(out), L.ptr(mu), L.ptr(sg), self._stream()),
                 self._ctx, "pu_sample")
         if _return_dist:
             return out, Independent(Normal(loc=mu, scale=sg), 1)
@@ -750,8 +892,9 @@ class ProbabilisticUNet(nn.Module):
             eps = torch.randn(n, B, self.latent_dim, device=x.device, dtype=torch.float32)
         eps = eps.contiguous().float()
         out = torch.empty(B, n, self.num_classes, H, W, device=x.device, dtype=torch.float32)
+        self._gen["unet"] += 1; self._gen["posterior" if target is not None else "prior"] += 1; self._touch_xin(x)
         L.check(L.lib().pu_sample_hr(self._ctx, L.ptr(x), L.ptr(target), L.ptr(eps), B, n, L.ptr(lrinterp), L.ptr(residual_std),
-                                     float(epsilon), 1 if softplus else 0, float(softplus_c), L.ptr(out), None, None, L.current_stream()),
+                                     float(epsilon), 1 if softplus else 0, float(softplus_c), L.ptr(out), None, None, self._stream()),
                 self._ctx, "pu_sample_hr")
         return out
 
@@ -844,16 +987,29 @@ def _param_table_host(m: ProbabilisticUNet):
 
 class FlatAdamW:
     """torch.optim.AdamW(model.parameters(), lr=1e-4) of the reference trainer (main.py:103) as ONE fused HIP pass over the
-    engine's flat parameter / gradient buffers (pu_adamw_step).  Same update rule and defaults as torch (betas 0.9/0.999,
-    eps 1e-8, weight_decay 0.01; dead parameters with zero gradient still decay).  Use: opt = FlatAdamW(model, lr=1e-4);
-    loss.backward(); opt.step(); opt.zero_grad()."""
+    engine's flat parameter / gradient buffers (pu_adamw_step_dev).  Same update rule and defaults as torch (betas 0.9/0.999,
+    eps 1e-8, weight_decay 0.01; parameters with a zero gradient still decay).  Use: opt = FlatAdamW(model, lr=1e-4);
+    loss.backward(); opt.step(); opt.zero_grad().
+
+    Semantics kept from torch: parameters whose .grad is None are skipped (no decay, no moment update; the update then runs per
+    contiguous range that has gradients); step() is a no-op when no parameter has a gradient.  One difference: the step counter
+    behind the bias corrections is global, not per parameter.
+    f16 engine: the step is skipped ON THE DEVICE when the gradients the optimizer is about to read contain inf / NaN (what
+    torch.cuda.amp.GradScaler does with a host sync); the step counter lives on the device and only advances on applied
+    updates, so the bias corrections match GradScaler's behaviour."""
 
     def __init__(self, model: ProbabilisticUNet, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
         self.model, self.lr, self.betas, self.eps, self.weight_decay = model, lr, betas, eps, weight_decay
-        self.step_count = 0
         self.skip_nonfinite = True        # f16 engine only: leave parameters untouched when the gradients overflowed (see step())
         self.exp_avg = None
         self.exp_avg_sq = None
+        self._state = None                # device [4]: applied updates, lr / bc1, 1 / sqrt(bc2), skip marker
+        self._flag = None                 # device [1]: non-finite flag of the gradients read by the current step
+
+    @property
+    def step_count(self) -> int:
+        """Number of APPLIED updates (device counter; reading it synchronises)."""
+        return 0 if self._state is None else int(self._state[0].item())
 
     def zero_grad(self, set_to_none: bool = True):
         for p in self.model.parameters():
@@ -865,22 +1021,44 @@ class FlatAdamW:
         if m._flat is None:
             raise L.ProbUNetLibraryError("FlatAdamW.step() before the first forward: the flat buffers do not exist yet")
         m._check_views()
-        if self.exp_avg is None or self.exp_avg.device != m._flat.device:
+        dev = m._flat.device
+        if self.exp_avg is None or self.exp_avg.device != dev:
             self.exp_avg = torch.zeros_like(m._flat); self.exp_avg_sq = torch.zeros_like(m._flat)
-        g0 = next(iter(m.parameters())).grad
-        if g0 is None:
+            self._state = torch.zeros(4, device=dev, dtype=torch.float32); self._flag = torch.zeros(1, device=dev, dtype=torch.float32)
+        # bring the flat gradient buffer in line with what p.grad says: views of it stay, foreign tensors are copied in;
+        # parameters whose .grad is None are left out of the update altogether (torch.optim skips them: no decay, no moment
+        # update) - their range of the flat buffer may still hold an earlier step's values and is never read
+        base = m._flat_grad.data_ptr()
+        runs = []                         # contiguous [lo, hi) runs of parameters that have a gradient
+        for p, off, n in m._params_in(0, m._nparams):
+            g = p.grad
+            if g is None:
+                continue
+            if g.data_ptr() != base + 4 * off or g.dtype != torch.float32:
+                m._flat_grad[off:off + n].copy_(g.reshape(-1))
+            if runs and runs[-1][1] == off:
+                runs[-1][1] = off + n
+            else:
+                runs.append([off, off + n])
+        if not runs:
             return
-        if g0.data_ptr() != m._flat_grad.data_ptr():             # gradients were accumulated outside the flat buffer
-            for p, off, n in m._params_in(0, m._nparams):
-                m._flat_grad[off:off + n].copy_((p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1))
-        self.step_count += 1
-        # f16 engine: the step is skipped ON THE DEVICE when the engine flagged non-finite gradients for the last elbo() (no host sync)
+        lib = L.lib()
         flag = None
-        sc = getattr(m, "_last_scalars", None)
-        if self.skip_nonfinite and m.compute_dtype in ("f16", "fp16", "float16") and sc is not None and sc.device == m._flat.device:
-            flag = C.c_void_p(sc.data_ptr() + 4 * L.PU_S_NONFINITE)
-            self._flag_owner = sc                                  # keep the scalars alive until the kernel has run
-        L.check(L.lib().pu_adamw_step_guarded(L.ptr(m._flat), L.ptr(m._flat_grad), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq), m._nparams,
-                                              float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
-                                              float(self.weight_decay), self.step_count, flag, L.current_stream()), m._ctx, "pu_adamw_step")
+        if self.skip_nonfinite and m.compute_dtype in ("f16", "fp16", "float16"):
+            # derived from the buffer this step reads (covers accumulation over several backward() calls and, under data
+            # parallelism, the averaged gradients: identical on every rank, so all ranks skip together)
+            self._flag.zero_()
+            for lo, hi in runs:
+                L.check(lib.pu_nonfinite_flag(C.c_void_p(base + 4 * lo), hi - lo, L.ptr(self._flag), m._stream()), m._ctx, "pu_nonfinite_flag")
+            flag = L.ptr(self._flag)
+        hyper = (float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay))
+        if len(runs) == 1 and runs[0] == [0, m._nparams]:
+            L.check(lib.pu_adamw_step_dev(L.ptr(m._flat), L.ptr(m._flat_grad), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq), m._nparams,
+                                          *hyper, L.ptr(self._state), flag, m._stream()), m._ctx, "pu_adamw_step_dev")
+        else:
+            L.check(lib.pu_adamw_prepare(L.ptr(self._state), flag, hyper[0], hyper[1], hyper[2], m._stream()), m._ctx, "pu_adamw_prepare")
+            for lo, hi in runs:
+                at = lambda t: C.c_void_p(t.data_ptr() + 4 * lo)
+                L.check(lib.pu_adamw_apply(at(m._flat), at(m._flat_grad), at(self.exp_avg), at(self.exp_avg_sq), hi - lo, *hyper,
+                                           L.ptr(self._state), m._stream()), m._ctx, "pu_adamw_apply")
         m._params_dirty()

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, initfile, outdir):
+def _worker(rank, world, initfile, outdir, buckets=4):
     sys.path.insert(0, ROOT)
     import probunet_amd as pa
     from tests.filler import make_fields, make_eps
@@ -21,13 +21,22 @@ def _worker(rank, world, initfile, outdir):
     torch.manual_seed(100 + rank)                                  # different initialisations: the broadcast must fix that
     m = pa.ProbabilisticUNet(2, 1, 4, [8, 16], 8, [1, 2], 0.7, 1.3, 0.0, dtype="f32").to(dev).train()
     m.dropout = 0.0
+    m.dp_overlap_buckets = buckets                                 # > 0: bucketed all-reduce issued by elbo() behind the engine's events
     m.enable_data_parallel()
     x, y = make_fields(4, 2, 1, 32, 32, seed=40); eps = make_eps(2, 4, 4)
     xs, ys = pa.dp.shard_batch(x, rank, world).contiguous().to(dev), pa.dp.shard_batch(y, rank, world).contiguous().to(dev)
     es = eps[:, rank * 2:(rank + 1) * 2].contiguous().to(dev)
     opt = pa.FlatAdamW(m, lr=1e-3)
     loss, _, _ = m.elbo(xs, ys, None, M=2, eps=es)
+    ranges = m._dp_bucket_ranges()
+    if buckets > 0:                                                # the buckets partition the flat buffer
+        assert m._dp_works is not None and len(m._dp_works) == len(ranges) >= 2
+        cover = sorted(ranges)
+        assert cover[0][0] == 0 and cover[-1][1] == m._nparams and all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
+    else:
+        assert m._dp_works is None and ranges == []
     opt.zero_grad(); loss.backward()
+    assert m._dp_works is None
     g = torch.cat([p.grad.flatten() for p in m.parameters()]).cpu()
     p0 = torch.cat([p.detach().flatten() for p in m.parameters()]).cpu()
     opt.step()
@@ -71,28 +80,48 @@ def _worker_overflow(rank, world, initfile, outdir):
     loss, _, _ = m.elbo(xs, ys, None, M=2, eps=eps[:, rank * 2:(rank + 1) * 2].contiguous().to(dev))
     opt.zero_grad(); loss.backward(); opt.step()
     p1 = torch.cat([p.detach().flatten() for p in m.parameters()]).cpu()
-    torch.save(dict(p0=p0, p1=p1, flag=float(m._last_scalars[L.PU_S_NONFINITE])), os.path.join(outdir, f"o{rank}.pt"))
+    torch.save(dict(p0=p0, p1=p1, flag=float(opt._flag), steps=opt.step_count), os.path.join(outdir, f"o{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_overflow_on_one_rank_makes_every_rank_skip():
-    """f16 engine, rank 1 overflows (absurd loss scale), rank 0 does not: the flag is MAX-reduced with the gradients, so both
-    ranks leave their (identical) parameters untouched instead of rank 0 applying a NaN-poisoned average."""
+    """f16 engine, rank 1 overflows (absurd loss scale), rank 0 does not: the SUM is non-finite on every rank, and the optimizer derives
+    its skip flag from the averaged buffer it reads, so both ranks leave their (identical) parameters untouched instead of rank 0
+    applying a NaN-poisoned average; the device step counter does not advance."""
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_worker_overflow, args=(2, os.path.join(d, "init"), d), nprocs=2, join=True)
         o0, o1 = torch.load(os.path.join(d, "o0.pt")), torch.load(os.path.join(d, "o1.pt"))
-    assert o0["flag"] == 1.0 and o1["flag"] == 1.0
+    assert o0["flag"] == 1.0 and o1["flag"] == 1.0 and o0["steps"] == 0 and o1["steps"] == 0
     assert torch.equal(o0["p0"], o0["p1"]) and torch.equal(o1["p0"], o1["p1"]) and torch.equal(o0["p1"], o1["p1"])
     assert torch.isfinite(o0["p1"]).all()
 
 
-def test_two_rank_model_path_on_one_gpu():
+@pytest.mark.parametrize("buckets", [4, 0])
+def test_two_rank_model_path_on_one_gpu(buckets):
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(2, os.path.join(d, "init"), d), nprocs=2, join=True)
+        mp.spawn(_worker, args=(2, os.path.join(d, "init"), d, buckets), nprocs=2, join=True)
         r0, r1, ref = torch.load(os.path.join(d, "r0.pt")), torch.load(os.path.join(d, "r1.pt")), torch.load(os.path.join(d, "ref.pt"))
     assert torch.equal(r0["p0"], r1["p0"])                          # broadcast from rank 0
     assert torch.equal(r0["g"], r1["g"])                            # both ranks hold the same averaged gradient
     err = float((r0["g"] - ref["g"]).abs().max()); scale = float(ref["g"].abs().max())
     assert err <= 2e-4 * scale + 1e-7, (err, scale)                 # == gradient of the global batch (fp32 engine, summation order only)
     assert torch.equal(r0["p1"], r1["p1"]) and not torch.equal(r0["p1"], r0["p0"])
+
+
+def test_bench_self_launch_two_rank_rehearsal():
+    """`python bench.py --gpus 2` with NO launcher around it: the script spawns torch.distributed.run on itself before touching the GPU.
+    PU_BENCH_REHEARSAL=1 puts both ranks on the one GPU of this box with gloo (RCCL refuses two ranks per device); a reduced batch keeps
+    the two replicas small.  Checks the JSON contract of the multi-rank line."""
+    import json, subprocess
+    env = dict(os.environ, PU_BENCH_REHEARSAL="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2",
+                        "--members", "2", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["config"]["world_size_seen_by_backend"] == 2 and out["config"]["backend"] == "gloo"
+    assert out["config"]["dp_gradient_buckets"] >= 2 and out["config"]["loss_finite"] is True
+    assert out["value"] > 0 and out["scaling"] == "weak" and out["config"]["global_batch"] == 4

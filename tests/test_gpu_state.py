@@ -1,0 +1,270 @@
+"""GPU: engine-state rules of the host class and the tolerance story.
+
+  * one forward in flight per engine: a backward() whose saved engine state was overwritten raises instead of silently
+    delivering another call's gradients (elbo twice, sub-module twice, prior(x') between unet(x) and its backward);
+  * FlatAdamW reads the gradients the way torch.optim does: parameters without .grad are skipped (never a stale range of the
+    flat buffer), an overflow anywhere in an ACCUMULATED gradient skips the step, the step counter only counts applied updates;
+  * injected dropout masks through the ABI (pu_set_drop_masks): train-mode ELBO forward + backward against
+    oracle.elbo(drop_masks=...) end to end;
+  * the fp32 engine against an fp64 evaluation of the oracle on RANDOM weights and inputs (no structured ties): strict
+    north_star tolerance rtol 1e-3 / atol 1e-5 WITHOUT max-abs scaling, and per tensor no worse than 3x what torch's own fp32
+    evaluation of the same graph achieves against fp64.
+"""
+import numpy as np
+import pytest, torch
+import probunet_amd as pa
+from probunet_amd import _lib as L
+from oracle import probunet_oracle as O
+from tests.helpers import filled_params, assert_close
+from tests.filler import make_fields, make_eps
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _small(dtype="f32", H=32, **kw):
+    cfg = O.Config(2, 1, 4, [8, 16], 8, [1, 2])
+    P = filled_params(cfg)
+    m = pa.ProbabilisticUNet(2, 1, 4, [8, 16], 8, [1, 2], 0.7, 1.3, 0.0, dtype=dtype, init=False, **kw)
+    m.load_state_dict(P)
+    m = m.to(DEV).train(); m.dropout = 0.0
+    return m, cfg, P
+
+
+def _flat(m):
+    return torch.cat([p.detach().flatten() for p in m.parameters()]).clone()
+
+
+# ------------------------------------------------------------------------------------------------ one forward in flight
+def test_second_elbo_before_backward_raises():
+    m, cfg, P = _small()
+    x, y = make_fields(2, 2, 1, 32, 32, seed=3); x, y = x.to(DEV), y.to(DEV); eps = make_eps(2, 2, 4).to(DEV)
+    l1, _, _ = m.elbo(x, y, None, M=2, eps=eps)
+    l2, _, _ = m.elbo(x * 0.5, y, None, M=2, eps=eps)
+    with pytest.raises(L.ProbUNetLibraryError, match="stale engine state"):
+        l1.backward()
+    l2.backward()                                                  # the latest call is still valid
+    g2 = torch.cat([p.grad.flatten() for p in m.parameters()]).clone()
+    m.zero_grad(set_to_none=True)
+    l3, _, _ = m.elbo(x * 0.5, y, None, M=2, eps=eps); l3.backward()
+    assert_close(torch.cat([p.grad.flatten() for p in m.parameters()]).cpu(), g2.cpu(), rtol=1e-5, atol=1e-7, what="gradient of the surviving call")
+    # a forward-only elbo (validation under no_grad) between backward-enabled elbo and its backward also overwrites the activations,
+    # but not the gradients the fused call already computed: that pattern stays legal
+    l4, _, _ = m.elbo(x, y, None, M=2, eps=eps)
+    with torch.no_grad():
+        m.elbo(x * 2.0, y, None, M=2, eps=eps)
+    m.zero_grad(set_to_none=True); l4.backward()
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters())
+
+
+def test_submodule_forward_twice_before_backward_raises():
+    m, cfg, P = _small()
+    x1, y = make_fields(2, 2, 1, 32, 32, seed=4); x1, y = x1.to(DEV), y.to(DEV); x2 = (x1 * 0.3).contiguous()
+    f1 = m.unet(x1); f2 = m.unet(x2)
+    with pytest.raises(L.ProbUNetLibraryError, match="stale engine state"):
+        (f1.sum() + f2.sum()).backward()
+    # prior(x') with a different x rewrites the shared input planes the U-Net stem's weight gradient reads
+    f = m.unet(x1); p = m.prior(x2)
+    with pytest.raises(L.ProbUNetLibraryError, match="stale engine state"):
+        f.sum().backward()
+    # the reference's own composition (prob_unet.py:194-224: unet -> posterior -> fcomb, same x) is untouched by the rule
+    m.zero_grad(set_to_none=True)
+    out = m(x1, y, training=True)
+    out.sum().backward()
+    assert m.unet.out_conv.weight.grad is not None and m.posterior.conv_mu.weight.grad is not None
+    m.zero_grad(set_to_none=True)
+    f = m.unet(x1); p = m.prior(x1)                                 # same x: the shared planes hold the same values
+    (f.sum() + p.base_dist.loc.sum()).backward()
+    assert m.prior.conv_mu.weight.grad is not None
+
+
+# ------------------------------------------------------------------------------------------------ FlatAdamW
+def test_flat_adamw_skips_parameters_without_grad_and_ignores_stale_ranges():
+    m, cfg, P = _small()
+    x, y = make_fields(2, 2, 1, 32, 32, seed=5); x, y = x.to(DEV), y.to(DEV); eps = make_eps(2, 2, 4).to(DEV)
+    opt = pa.FlatAdamW(m, lr=1e-2)
+    ref = pa.ProbabilisticUNet(2, 1, 4, [8, 16], 8, [1, 2], 0.7, 1.3, 0.0, dtype="f32", init=False)
+    ref.load_state_dict(P); ref = ref.to(DEV).train(); ref.dropout = 0.0
+    topt = torch.optim.AdamW(ref.parameters(), lr=1e-2)
+    for mm, oo in ((m, opt), (ref, topt)):
+        loss, _, _ = mm.elbo(x, y, None, M=2, eps=eps)
+        oo.zero_grad(); loss.backward(); oo.step()                  # step 1: every parameter has a gradient
+        oo.zero_grad()
+        pr = mm.prior(x)                                            # step 2: a loss that only reaches the prior encoder
+        (pr.base_dist.loc.sum() + pr.base_dist.scale.sum()).backward()
+        before = {k: p.detach().clone() for k, p in mm.named_parameters()}
+        oo.step()
+        moved = {k: not torch.equal(before[k], p.detach()) for k, p in mm.named_parameters()}
+        assert all(moved[k] for k in moved if k.startswith("prior.")), "prior parameters must move"
+        assert not any(moved[k] for k in moved if not k.startswith("prior.")), [k for k in moved if moved[k] and not k.startswith("prior.")][:3]
+    # and the two optimizers agree on the result (same rule; the flat one keeps ONE global step counter, equal here)
+    for (k, p), (_, q) in zip(m.named_parameters(), ref.named_parameters()):
+        assert_close(p.detach().cpu(), q.detach().cpu(), rtol=1e-4, atol=1e-6, what=k)
+    assert opt.step_count == 2
+    # no gradient anywhere: a no-op
+    opt.zero_grad(); p0 = _flat(m); opt.step(); assert torch.equal(p0, _flat(m)) and opt.step_count == 2
+
+
+def test_overflow_in_an_accumulated_micro_batch_skips_the_step():
+    """f16 engine, gradient accumulation over two backward() calls: the FIRST micro-batch overflows (absurd loss scale), the
+    second is clean.  The flag the optimizer uses is derived from the accumulated buffer it reads, so the step is skipped and
+    the device-side step counter does not advance; a clean accumulation afterwards is applied."""
+    m, cfg, P = _small("f16")
+    x, y = make_fields(2, 2, 1, 32, 32, seed=6); x, y = x.to(DEV), y.to(DEV); eps = make_eps(2, 2, 4).to(DEV)
+    opt = pa.FlatAdamW(m, lr=1e-2)
+    p0 = _flat(m)
+    opt.zero_grad()
+    m.grad_scale = 2.0 ** 40
+    l1, _, _ = m.elbo(x, y, None, M=2, eps=eps); l1.backward()
+    assert not all(torch.isfinite(p.grad).all() for p in m.parameters())
+    m.grad_scale = 0.0
+    l2, _, _ = m.elbo(x, y, None, M=2, eps=eps); l2.backward()      # accumulates onto the poisoned gradients; its own flag is 0
+    assert float(m._last_scalars[L.PU_S_NONFINITE]) == 0.0
+    opt.step()
+    assert torch.equal(p0, _flat(m)) and float(opt.exp_avg.abs().sum()) == 0.0 and opt.step_count == 0
+    assert float(opt._flag) == 1.0
+    opt.zero_grad()
+    l3, _, _ = m.elbo(x, y, None, M=2, eps=eps); l3.backward()
+    l4, _, _ = m.elbo(x, y, None, M=2, eps=eps); l4.backward()
+    opt.step()
+    assert not torch.equal(p0, _flat(m)) and torch.isfinite(_flat(m)).all() and opt.step_count == 1 and float(opt._flag) == 0.0
+
+
+def test_create_restores_the_callers_device_and_stream_is_the_models():
+    m, cfg, P = _small()
+    before = torch.cuda.current_device()
+    x, y = make_fields(1, 2, 1, 32, 32, seed=7)
+    with torch.no_grad():
+        m.elbo(x.to(DEV), y.to(DEV), None, M=2, eps=make_eps(2, 1, 4).to(DEV))
+    assert torch.cuda.current_device() == before
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s), torch.no_grad():                     # work follows torch's current stream on the model's device
+        a = m.sample(x.to(DEV), 2, eps=make_eps(2, 1, 4).to(DEV))
+    s.synchronize()
+    with torch.no_grad():
+        b = m.sample(x.to(DEV), 2, eps=make_eps(2, 1, 4).to(DEV))
+    assert torch.equal(a, b)
+
+
+# ------------------------------------------------------------------------------------------------ injected dropout masks
+@pytest.mark.parametrize("dtype", ["f32", "f16"])
+def test_train_mode_with_injected_dropout_masks_matches_oracle(dtype):
+    """networks.py:177 (`dropout(silu(...))`, p = 0.10, training): the masks are drawn here with torch's CPU generator, handed to
+    the oracle (drop_masks=) and to the engine (model.set_drop_masks -> pu_set_drop_masks), forward AND backward."""
+    cfg = O.Config(4, 1, 6, [8, 16, 32], 8, [1, 2, 4])
+    P = filled_params(cfg)
+    B, H = 2, 32
+    x, y = make_fields(B, 4, 1, H, H, seed=8); eps = make_eps(3, B, 6)
+    enc, dec = O.unet_layout(cfg)
+    g = torch.Generator().manual_seed(123)
+    masks = {}
+    for b in enc + dec:
+        if b.kind == "block":
+            lv = int(b.name.split(".")[2].split("x")[0])
+            r = H * lv // 128
+            masks[b.name] = (torch.rand(B, b.cout, r, r, generator=g) >= cfg.dropout).float()
+    ref, og = O.elbo_with_grads(P, cfg, x, y, eps, beta0=0.7, beta1=1.3, drop_masks=masks)
+    ref0, _ = O.elbo_with_grads(P, cfg, x, y, eps, beta0=0.7, beta1=1.3)
+    assert abs(float(ref["total"]) - float(ref0["total"])) > 1e-4          # the masks matter
+    m = pa.ProbabilisticUNet(4, 1, 6, [8, 16, 32], 8, [1, 2, 4], 0.7, 1.3, 0.0, dtype=dtype, init=False)
+    m.load_state_dict(P); m = m.to(DEV).train()
+    assert abs(m.dropout - cfg.dropout) < 1e-12
+    m.set_drop_masks(masks)
+    total, recon, kl = m.elbo(x.to(DEV), y.to(DEV), None, M=3, eps=eps.to(DEV))
+    total.backward()
+    if dtype == "f32":
+        assert_close(total.detach().cpu(), ref["total"], what="total (train mode, injected masks)")
+        assert_close(recon[0], ref["recon"], what="afcrps"); assert_close(kl.cpu(), ref["kl"], what="kl")
+        for k, p in m.named_parameters():
+            v = og[k]
+            assert_close(p.grad.cpu(), v, rtol=1e-3, atol=1e-5 + 2e-3 * float(v.abs().mean()), what="grad " + k)
+        feat = m.unet(x.to(DEV)).detach().cpu()                             # sub-module path uses the same masks
+        assert_close(feat, O.unet_forward(P, cfg, x, masks), what="unet(x) with masks")
+    else:
+        assert_close(recon[0], ref["recon"], rtol=3e-2, atol=2e-2, what="afcrps f16")
+        num = da = db = 0.0
+        for k, p in m.named_parameters():
+            a, b_ = p.grad.detach().cpu().double().flatten(), og[k].double().flatten()
+            num += float(a @ b_); da += float(a @ a); db += float(b_ @ b_)
+        assert num / np.sqrt(da * db) > 0.97
+    # clearing the masks returns to the engine's own stream: a different draw, hence a different loss
+    m.set_drop_masks(None)
+    with torch.no_grad():
+        t2, _, _ = m.elbo(x.to(DEV), y.to(DEV), None, M=3, eps=eps.to(DEV))
+    assert abs(float(t2) - float(total.detach())) > 1e-5
+    with pytest.raises(ValueError):
+        m.set_drop_masks({k: v for k, v in list(masks.items())[:-1]})       # every site needs a mask
+
+
+# ------------------------------------------------------------------------------------------------ tolerance story
+def _random_params(cfg, seed):
+    """Random (non closed-form) parameters: kaiming-scaled normals, GroupNorm affine around (1, 0), non-zero everything."""
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for name, shp in O.param_shapes(cfg).items():
+        if name.endswith("resample_filter"):
+            out[name] = torch.full(tuple(shp), 0.25)
+        elif len(shp) == 4:
+            fan_in = shp[1] * shp[2] * shp[3]
+            out[name] = torch.randn(shp, generator=g) * (1.0 / fan_in) ** 0.5
+        elif len(shp) == 2:
+            out[name] = torch.randn(shp, generator=g) * 0.05
+        elif name.endswith("norm0.weight") or name.endswith("norm1.weight") or name.endswith("out_norm.weight"):
+            out[name] = 1.0 + 0.1 * torch.randn(shp, generator=g)
+        else:
+            out[name] = 0.05 * torch.randn(shp, generator=g)
+    return out
+
+
+@pytest.fixture(scope="module")
+def cfg1_random():
+    """BASELINE cfg1 (1 -> 1, 64 x 64, depth-3 [32, 64, 128], latent 6, B = 4, M = 5) with random weights and N(0, 1) fields."""
+    cfg = O.Config(1, 1, 6, [32, 64, 128], 32, [1, 2, 4])
+    P = _random_params(cfg, 11)
+    g = torch.Generator().manual_seed(1234)
+    x = torch.randn(4, 1, 64, 64, generator=g); y = torch.randn(4, 1, 64, 64, generator=g); eps = torch.randn(5, 4, 6, generator=g)
+    r64, g64 = O.elbo_with_grads({k: v.double() for k, v in P.items()}, cfg, x.double(), y.double(), eps.double(), beta0=0.7, beta1=1.3)
+    r32, g32 = O.elbo_with_grads(P, cfg, x, y, eps, beta0=0.7, beta1=1.3)
+    m = pa.ProbabilisticUNet(1, 1, 6, [32, 64, 128], 32, [1, 2, 4], 0.7, 1.3, 0.0, dtype="f32", init=False)
+    m.load_state_dict(P); m = m.to(DEV).train(); m.dropout = 0.0
+    total, recon, kl = m.elbo(x.to(DEV), y.to(DEV), None, M=5, eps=eps.to(DEV))
+    total.backward()
+    gh = {k: p.grad.detach().cpu() for k, p in m.named_parameters()}
+    with torch.no_grad():
+        feat = m.eval().unet(x.to(DEV)).cpu()
+    return dict(r64=r64, g64=g64, r32=r32, g32=g32, gh=gh, total=float(total.detach()), recon=recon[0], kl=kl.cpu(), feat=feat)
+
+
+def _strict_close(a, b, what, rtol=1e-3, atol=1e-5):
+    a = torch.as_tensor(a).double(); b = torch.as_tensor(b).double()
+    err = (a - b).abs(); tol = atol + rtol * b.abs()                        # NO max-abs scaling of atol
+    assert bool((err <= tol).all()), (what, float(err.max()), float((err - tol).max()), float((err > tol).double().mean()))
+
+
+def test_cfg1_random_weights_strict_north_star_tolerance(cfg1_random):
+    d = cfg1_random
+    _strict_close(d["total"], d["r64"]["total"], "total"); _strict_close(d["recon"], d["r64"]["recon"], "afcrps")
+    _strict_close(d["kl"], d["r64"]["kl"], "kl"); _strict_close(d["feat"], d["r64"]["feat"], "unet features")
+    for k, v in d["g64"].items():
+        _strict_close(d["gh"][k], v, "grad " + k)
+
+
+def test_cfg1_hip_fp32_is_as_close_to_fp64_as_torch_fp32(cfg1_random):
+    """Per tensor: relative L2 error of the HIP fp32 engine's gradient against the fp64 evaluation <= 3 x the error of torch's
+    own fp32 evaluation of the same graph + 1e-6 (the fp32 noise floor).  Different summation orders (MFMA 32x32x2 chains, two-level
+    chunk sums) may lose or win by small factors; a systematic precision loss (a 16-bit intermediate, a cancellation in the
+    GroupNorm statistics) would show as orders of magnitude."""
+    d = cfg1_random
+    worst = []
+    for k, ref in d["g64"].items():
+        n = float(ref.norm())
+        if n < 1e-12:
+            assert float(d["gh"][k].abs().max()) < 1e-9, k
+            continue
+        eh = float((d["gh"][k].double() - ref).norm()) / n
+        et = float((d["g32"][k].double() - ref).norm()) / n
+        worst.append((eh / (3 * et + 1e-6), k, eh, et))
+    worst.sort(reverse=True)
+    assert worst[0][0] <= 1.0, worst[:5]
+    med_h = float(np.median([w[2] for w in worst])); med_t = float(np.median([w[3] for w in worst]))
+    assert med_h <= 2.0 * med_t + 1e-6, (med_h, med_t)

@@ -95,13 +95,15 @@ def test_no_cpu_fallback():
 
 
 def test_library_exports_every_declared_symbol():
-    hdr = open(os.path.join(ROOT, "include", "probunet.h")).read()
-    names = sorted(set(re.findall(r"\b(pu_[a-z0-9_]+)\s*\(", hdr)))
-    assert len(names) >= 20
     lib = ctypes.CDLL(L.LIB_PATH)
-    for n in names:
-        assert hasattr(lib, n), f"{n} declared in include/probunet.h but not exported"
-    assert L.lib().pu_abi_version() == 1
+    for header, least in (("probunet.h", 35), ("probunet_testing.h", 4)):       # product ABI; test / micro-benchmark hooks
+        hdr = open(os.path.join(ROOT, "include", header)).read()
+        names = sorted(set(re.findall(r"\b(pu_[a-z0-9_]+)\s*\(", hdr)))
+        assert len(names) >= least, (header, len(names))
+        for n in names:
+            assert hasattr(lib, n), f"{n} declared in include/{header} but not exported"
+    assert "pu_op_conv" not in open(os.path.join(ROOT, "include", "probunet.h")).read().replace("pu_op_*", "")
+    assert L.lib().pu_abi_version() == 2
     assert ctypes.sizeof(L.PuConfig) == 4 * (4 + 8 + 1 + 8 + 2 + 2 + 1) + 4 + 4
     assert ctypes.sizeof(L.PuParamDesc) == 96 + 4 + 16 + 4 + 8 + 8 or ctypes.sizeof(L.PuParamDesc) % 8 == 0
 

@@ -78,3 +78,33 @@ def test_afcrps_needs_two_members():
     cfg = oracle_cfg(meta["config"])
     with pytest.raises(ValueError):
         O.elbo(filled_params(cfg), cfg, t(g["x"]), t(g["y"]), t(g["eps"])[:1], beta0=1, beta1=1)
+
+
+def test_climex_transforms_match_reference():
+    """Rows f3 / f4: tests/golden/climex.npz holds outputs of the imported src/climex_utils.py (tools/make_golden_climex.py):
+    softplus / softplus_inv (:36-46), compute_stats (:255-264), the item transform (:197-250), invstand_residual and
+    residual_to_hr (:270-285).  Pure fp32 arithmetic of a handful of ops: rtol 1e-6 on the statistics, exact elsewhere up to
+    the last ulp of the division."""
+    import os
+    import numpy as np
+    from tests.helpers import GOLDEN
+    g = dict(np.load(os.path.join(GOLDEN, "climex.npz")))
+    k = int(g["k"]); hr = t(g["hr"])
+    assert_close(O.softplus_climex(t(g["sp_in"])), g["sp_out"], rtol=1e-6, atol=1e-7, what="softplus")
+    assert_close(O.softplus_climex(t(g["sp_in"]), c=0.), g["sp_out_c0"], rtol=1e-6, atol=1e-7, what="softplus c=0")
+    assert_close(O.softplus_inv_climex(t(g["spinv_in"])), g["spinv_out"], rtol=1e-6, atol=1e-7, what="softplus_inv")
+    assert_close(O.softplus_inv_climex(t(g["spinv_in"]), c=0.), g["spinv_out_c0"], rtol=1e-6, atol=1e-7, what="softplus_inv c=0")
+    (ml, sl), (mh, sh) = O.lr_stats(hr, k)
+    for mine, key in ((ml, "mean_lr"), (sl, "std_lr"), (mh, "mean_hr"), (sh, "std_hr")):
+        assert_close(mine, g[key], rtol=1e-6, atol=1e-7, what=key)
+    it = O.lrinterp_to_residuals(hr[:3], k, mh, sh, 1e-10)
+    for key in ("inputs", "targets", "lrinterp", "lr"):
+        assert_close(it[key], g["item_" + key], rtol=1e-6, atol=1e-6, what="item " + key)
+    assert_close(O.invstand_residual(t(g["item_targets"]), mh, sh), g["invstand_residual"], rtol=1e-6, atol=1e-7, what="invstand_residual")
+    assert_close(O.residual_to_hr(t(g["item_targets"]), t(g["item_lrinterp"]), sh), g["residual_to_hr"], rtol=1e-6, atol=1e-6, what="residual_to_hr")
+    assert_close(O.residual_to_hr(t(g["pred_residual"]), t(g["item_lrinterp"]), sh), g["pred_to_hr"], rtol=1e-6, atol=1e-6, what="residual_to_hr 5-D")
+    assert_close(O.invstand_residual(t(g["hrkind_targets"]), mh, sh, kind="lrinterp_to_hr"), g["hrkind_invstand"], rtol=1e-6, atol=1e-6,
+                 what="invstand (hr kind)")
+    # the hr-kind item: inputs are the same standardised lrinterp, targets the standardised hr
+    assert_close(it["inputs"][:2], g["hrkind_inputs"], rtol=1e-6, atol=1e-6, what="hr-kind inputs")
+    assert_close(it["inputs"][:2] + it["targets"][:2], g["hrkind_targets"], rtol=1e-5, atol=1e-5, what="hr-kind targets")
