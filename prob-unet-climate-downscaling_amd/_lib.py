@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libprobunet.so")
+LIB_PATH = os.environ.get("PU_LIB_PATH") or os.path.join(_HERE, "libprobunet.so")   # PU_LIB_PATH: diagnostic builds (tools/ablate_conv.sh)
 
 PU_MAX_LEVELS = 8
 PU_F32, PU_F16, PU_BF16 = 0, 1, 2

@@ -1401,6 +1401,12 @@ done:
   return rc;
 }
 
+// uniform 16-bit random values in [-1, 1) (bench on random data: zero / constant operands run at a higher clock, MI355X_MICROARCH.md DVFS)
+template <typename T>
+__global__ void rand_fill_kernel(T* p, long n, uint32_t seed) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    ET<T>::st(p + i, (float)(int)(hash32((uint32_t)i * 2654435761u + seed) >> 8) * (1.0f / 8388608.0f) - 1.0f);
+}
 // micro-benchmark of one convolution launch on random NHWC data (no layout conversion in the timed region)
 template <typename T>
 static int bench_conv_t(int mode, int ks, int B, int Cin, int Cout, int H, int W, int iters, float* out_us, hipStream_t s) {
@@ -1413,8 +1419,10 @@ static int bench_conv_t(int mode, int ks, int B, int Cin, int Cout, int H, int W
   const long nw = (long)Cout * Cin * taps;
   CK0(hipMalloc(&xin, npix * Cin * esz)); CK0(hipMalloc(&yb, npix * Cout * esz)); CK0(hipMalloc(&wf, nw * 4)); CK0(hipMalloc(&dw, nw * 4));
   CK0(hipMalloc(&dd, sizeof(PackDesc))); CK0(hipMalloc(&slab, 32L * 1024 * 1024 * 4));
-  CK0(launch_fill(wf, 0.01f, nw, s));
-  CK0(hipMemsetAsync(xin, 0x3c, npix * Cin * esz, s)); CK0(hipMemsetAsync(yb, 0x3c, npix * Cout * esz, s));   // ~1.0 in f16 / small in bf16
+  hipLaunchKernelGGL(rand_fill_kernel<float>, dim3(1024), dim3(256), 0, s, wf, nw, 11u);
+  hipLaunchKernelGGL(rand_fill_kernel<T>, dim3(4096), dim3(256), 0, s, xin, npix * Cin, 22u);
+  hipLaunchKernelGGL(rand_fill_kernel<T>, dim3(4096), dim3(256), 0, s, yb, npix * Cout, 33u);
+  CK0(hipGetLastError());
   CK0(hipEventCreate(&e0)); CK0(hipEventCreate(&e1));
   if (mode == 0 || mode == 1) {
     const int ci = mode == 0 ? Cin : Cout, co = mode == 0 ? Cout : Cin;

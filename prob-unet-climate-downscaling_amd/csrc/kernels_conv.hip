@@ -100,6 +100,13 @@ template <> __device__ __forceinline__ void store4<bf16>(bf16* p, const float* o
 
 constexpr int KC = 32;     // channels staged per K chunk
 
+// Diagnostic builds only (tools/ablate_conv.sh compiles extra copies of the library with -DPU_ABLATE=<bits>; results are wrong by
+// design, only the timing is read): 1 = weight fragments always from chunk 0 of tile 0 (L1/L2-hot), 2 = halo tile staged once,
+// 4 = no block barriers in the chunk loop, 8 = no LDS fragment reads, 16 = no output stores.  Production: 0.
+#ifndef PU_ABLATE
+#define PU_ABLATE 0
+#endif
+
 // ------------------------------------------------------------------ forward / dgrad implicit GEMM
 // Block = 64*WM*WN threads; pixel tile TH x TW (BM = TH*TW pixels, BM/WM per wave in 32-pixel MFMA columns);
 // cout tile BN = 32*NTN*WN.  K loop over 32-channel chunks: the global loads of chunk c+1 are issued into registers
@@ -395,7 +402,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3_kernel(ConvArgs a) {
   const T* wbase = have_w ? wfrag : reinterpret_cast<const T*>(a.wpk) + l * 8;     // idle waves read tile 0 (never stored)
   auto wload = [&](int c, int t, int kk) -> typename M::Frag {
     union { V16 v; typename M::Frag f; } u;
-    u.v = *reinterpret_cast<const V16*>(wbase + ((size_t)(c * TAPS + t) * 2 + kk) * 512);
+    if (PU_ABLATE & 1) c = 0;
+    u.v = *reinterpret_cast<const V16*>(((PU_ABLATE & 1) ? reinterpret_cast<const T*>(a.wpk) + l * 8 : wbase) + ((size_t)(c * TAPS + t) * 2 + kk) * 512);
     return u.f;
   };
   int pbase[NTM];
@@ -414,13 +422,17 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3_kernel(ConvArgs a) {
   for (int c = 0; c < nch; ++c) {
     const bool more = c + 1 < nch;
     const int cn = more ? c + 1 : c;               // the last chunk harmlessly re-reads its own fragments
-    if (more) gload((c + 1) * KC);
+    if (more && !(PU_ABLATE & 2)) gload((c + 1) * KC);
     const T* sb = sIn + cur * BUF;
     // software-pipelined over the 2*TAPS (tap, k-step) groups: the NTM LDS fragment reads of group g+1 are issued between
     // the MFMAs of group g (one ds_read_b128 per MFMA slot), so no MFMA waits on a read issued right before it
     typename M::Frag fb[2][NTM];
 #pragma unroll
     for (int j = 0; j < NTM; ++j) fb[0][j] = *reinterpret_cast<const typename M::Frag*>(sb + pbase[j]);
+    if (PU_ABLATE & 8) {
+#pragma unroll
+      for (int j = 0; j < NTM; ++j) fb[1][j] = fb[0][j];
+    }
 #pragma unroll
     for (int g = 0; g < 2 * TAPS; ++g) {
       const int t = g >> 1, kk = g & 1;
@@ -428,7 +440,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3_kernel(ConvArgs a) {
         const int t1 = (g + 1) >> 1, kk1 = (g + 1) & 1;
         const int toff1 = ((t1 / KS) * IW + (t1 % KS)) * KCP + kk1 * 16;
 #pragma unroll
-        for (int j = 0; j < NTM; ++j) fb[(g + 1) & 1][j] = *reinterpret_cast<const typename M::Frag*>(sb + pbase[j] + toff1);
+        for (int j = 0; j < NTM; ++j) if (!(PU_ABLATE & 8)) fb[(g + 1) & 1][j] = *reinterpret_cast<const typename M::Frag*>(sb + pbase[j] + toff1);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -437,10 +449,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3_kernel(ConvArgs a) {
       __builtin_amdgcn_sched_barrier(0);           // keep [reads of g+1 | MFMAs of g | weight refill] as issued: the reads land
                                                    // under the 8 MFMAs instead of being sunk next to their consumers
     }
-    if (more) lstore(cur ^ 1);
-    __syncthreads();
-    cur ^= 1;
+    if (more && !(PU_ABLATE & 2)) lstore(cur ^ 1);
+    if (!(PU_ABLATE & 4)) __syncthreads();
+    if (!(PU_ABLATE & 2)) cur ^= 1;
   }
+  if (PU_ABLATE & 4) __syncthreads();
 
   // ---- epilogue: D[row = cout][col = pixel] -> (+bias) -> wave-private LDS tile [pixel][32 couts] (80-byte rows) ->
   //      16-byte rows per lane: residual / accumulate / ReLU in the 16-byte domain, fully coalesced 64-byte runs per pixel
@@ -493,7 +506,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3_kernel(ConvArgs a) {
         for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
       }
       const V16 pk = pack<T>(v);
-      *reinterpret_cast<V16*>(out + pix * a.out_ld + co) = pk;
+      if (!(PU_ABLATE & 16) || pk.w[0] == 0x12345678u) *reinterpret_cast<V16*>(out + pix * a.out_ld + co) = pk;
       if (a.stat_out) {                                      // statistics of the values as stored (rounded to T)
         float w[8]; unpack<T>(pk, w);
 #pragma unroll

@@ -36,6 +36,25 @@ def filled_params(cfg: "O.Config"):
     return out
 
 
+def random_params(cfg, seed):
+    """Random (non closed-form) parameters: kaiming-scaled normals, GroupNorm affine around (1, 0), non-zero everything."""
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for name, shp in O.param_shapes(cfg).items():
+        if name.endswith("resample_filter"):
+            out[name] = torch.full(tuple(shp), 0.25)
+        elif len(shp) == 4:
+            fan_in = shp[1] * shp[2] * shp[3]
+            out[name] = torch.randn(shp, generator=g) * (1.0 / fan_in) ** 0.5
+        elif len(shp) == 2:
+            out[name] = torch.randn(shp, generator=g) * 0.05
+        elif name.endswith("norm0.weight") or name.endswith("norm1.weight") or name.endswith("out_norm.weight"):
+            out[name] = 1.0 + 0.1 * torch.randn(shp, generator=g)
+        else:
+            out[name] = 0.05 * torch.randn(shp, generator=g)
+    return out
+
+
 def t(a):
     return torch.from_numpy(np.asarray(a))
 

@@ -15,7 +15,7 @@ import pytest, torch
 import probunet_amd as pa
 from probunet_amd import _lib as L
 from oracle import probunet_oracle as O
-from tests.helpers import filled_params, assert_close
+from tests.helpers import filled_params, random_params, assert_close
 from tests.filler import make_fields, make_eps
 
 pytestmark = pytest.mark.gpu
@@ -190,37 +190,18 @@ def test_train_mode_with_injected_dropout_masks_matches_oracle(dtype):
     # clearing the masks returns to the engine's own stream: a different draw, hence a different loss
     m.set_drop_masks(None)
     with torch.no_grad():
-        t2, _, _ = m.elbo(x.to(DEV), y.to(DEV), None, M=3, eps=eps.to(DEV))
-    assert abs(float(t2) - float(total.detach())) > 1e-5
+        t2, r2, _ = m.elbo(x.to(DEV), y.to(DEV), None, M=3, eps=eps.to(DEV))
+    assert abs(r2[0] - recon[0]) > 1e-5 * abs(recon[0])          # (the KL-dominated total is too coarse in fp32 to show it)
     with pytest.raises(ValueError):
         m.set_drop_masks({k: v for k, v in list(masks.items())[:-1]})       # every site needs a mask
 
 
 # ------------------------------------------------------------------------------------------------ tolerance story
-def _random_params(cfg, seed):
-    """Random (non closed-form) parameters: kaiming-scaled normals, GroupNorm affine around (1, 0), non-zero everything."""
-    g = torch.Generator().manual_seed(seed)
-    out = {}
-    for name, shp in O.param_shapes(cfg).items():
-        if name.endswith("resample_filter"):
-            out[name] = torch.full(tuple(shp), 0.25)
-        elif len(shp) == 4:
-            fan_in = shp[1] * shp[2] * shp[3]
-            out[name] = torch.randn(shp, generator=g) * (1.0 / fan_in) ** 0.5
-        elif len(shp) == 2:
-            out[name] = torch.randn(shp, generator=g) * 0.05
-        elif name.endswith("norm0.weight") or name.endswith("norm1.weight") or name.endswith("out_norm.weight"):
-            out[name] = 1.0 + 0.1 * torch.randn(shp, generator=g)
-        else:
-            out[name] = 0.05 * torch.randn(shp, generator=g)
-    return out
-
-
 @pytest.fixture(scope="module")
 def cfg1_random():
     """BASELINE cfg1 (1 -> 1, 64 x 64, depth-3 [32, 64, 128], latent 6, B = 4, M = 5) with random weights and N(0, 1) fields."""
     cfg = O.Config(1, 1, 6, [32, 64, 128], 32, [1, 2, 4])
-    P = _random_params(cfg, 11)
+    P = random_params(cfg, 11)
     g = torch.Generator().manual_seed(1234)
     x = torch.randn(4, 1, 64, 64, generator=g); y = torch.randn(4, 1, 64, 64, generator=g); eps = torch.randn(5, 4, 6, generator=g)
     r64, g64 = O.elbo_with_grads({k: v.double() for k, v in P.items()}, cfg, x.double(), y.double(), eps.double(), beta0=0.7, beta1=1.3)
