@@ -352,6 +352,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3_kernel(ConvArgs a) {
   const int tid = threadIdx.x, l = tid & 63, wave = tid >> 6;
   const int wm = wave % WM, wn = wave / WM;
   const int tiles_x = a.W / TW, tiles_y = a.H / TH;
+#if PU_ABLATE & 32
+  const uint64_t ts0 = __builtin_amdgcn_s_memtime(), tr0 = __builtin_amdgcn_s_memrealtime();
+  uint64_t ts1 = 0, ts2 = 0;
+#endif
   int pt = blockIdx.x;
   if ((gridDim.x & 7) == 0) pt = (pt & 7) * (gridDim.x >> 3) + (pt >> 3);   // XCD-aware: each XCD (L2) gets a contiguous band of
                                                                              // pixel tiles, so halo rows are re-read from its own L2
@@ -418,6 +422,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3_kernel(ConvArgs a) {
   for (int t = 0; t < TAPS; ++t) { fa[t][0] = wload(0, t, 0); fa[t][1] = wload(0, t, 1); }
   lstore(0);
   __syncthreads();
+#if PU_ABLATE & 32
+  ts1 = __builtin_amdgcn_s_memtime();
+#endif
   int cur = 0;
   for (int c = 0; c < nch; ++c) {
     const bool more = c + 1 < nch;
@@ -454,6 +461,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3_kernel(ConvArgs a) {
     if (!(PU_ABLATE & 2)) cur ^= 1;
   }
   if (PU_ABLATE & 4) __syncthreads();
+#if PU_ABLATE & 32
+  ts2 = __builtin_amdgcn_s_memtime();
+#endif
 
   // ---- epilogue: D[row = cout][col = pixel] -> (+bias) -> wave-private LDS tile [pixel][32 couts] (80-byte rows) ->
   //      16-byte rows per lane: residual / accumulate / ReLU in the 16-byte domain, fully coalesced 64-byte runs per pixel
@@ -520,6 +530,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3_kernel(ConvArgs a) {
     const int co = ct * 32 + (l & 3) * 8;
     wave_stat_store(s1, s2, l, a.stat_out + (((size_t)b * slots + slot) * a.Cout + co) * 2, co < a.Cout);
   }
+#if PU_ABLATE & 32
+  {
+    const uint64_t ts3 = __builtin_amdgcn_s_memtime(), tr3 = __builtin_amdgcn_s_memrealtime();
+    if (l == 0 && (blockIdx.x % 97) == 0 && blockIdx.y == 0 && wave == 0)
+      printf("blk %4d nch %2d: prologue %6llu loop %7llu (%6llu per chunk) epilogue %6llu cycles; clock %.3f GHz\n", (int)blockIdx.x, nch,
+             (unsigned long long)(ts1 - ts0), (unsigned long long)(ts2 - ts1), (unsigned long long)((ts2 - ts1) / nch), (unsigned long long)(ts3 - ts2),
+             (double)(ts3 - ts0) / (double)(tr3 - tr0) * 0.1);
+  }
+#endif
 }
 
 // ------------------------------------------------------------------ conv3p: persistent variant for K <= 64 input channels

@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 template <typename T, int KS, int TH, int TW, int BCI, int NW = 4>
-static hipError_t launch_wg16(const WgradArgs& a, hipStream_t s) {
+static hipError_t launch_wg16(const WgradArgs& a, hipStream_t s, WgradReduce* red) {
   constexpr int PADP = KS / 2, BM = TH * TW, NPH = (TH + 2 * PADP) * (TW + 2 * PADP), TAPS = KS * KS;
   constexpr size_t lds = (size_t)2 * (2 * BM + (BCI / 32) * NPH) * 32 * 2;
   auto kern = conv_wgrad16_kernel<T, KS, TH, TW, BCI, NW>;
@@ -291,33 +291,48 @@ static hipError_t launch_wg16(const WgradArgs& a, hipStream_t s) {
   }
   hipLaunchKernelGGL(kern, dim3(split, gy, gz), dim3(64 * NW), lds, s, b);
   if (prof) prof_record(tag, 0, 0, s, false);
-  const long total = (long)TAPS * a.Cout * a.Cin;
-  const unsigned nbias_blocks = a.dbias0 ? (unsigned)cdiv(a.Cout, 64) : 0u;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64) + nbias_blocks), dim3(256), 0, s, a.slab, split, TAPS,
-                     gy * WBCO, gz * BCI, a.Cout, a.Cin, a.dw, a.inv_scale, a.dbias0, a.dbias1, a.inv_scale_dev);
+  red->slab = a.slab; red->split = split; red->taps = TAPS; red->cout_pad = gy * WBCO; red->cin_pad = gz * BCI; red->Cout = a.Cout; red->Cin = a.Cin;
+  red->dw = a.dw; red->inv_scale = a.inv_scale; red->db0 = a.dbias0; red->db1 = a.dbias1; red->inv_dev = a.inv_scale_dev;
+  return hipGetLastError();
+}
+hipError_t launch_wgrad16_reduce(const WgradReduce& r, hipStream_t s) {
+  const long total = (long)r.taps * r.Cout * r.Cin;
+  const unsigned nbias_blocks = r.db0 ? (unsigned)cdiv(r.Cout, 64) : 0u;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64) + nbias_blocks), dim3(256), 0, s, r.slab, r.split, r.taps,
+                     r.cout_pad, r.cin_pad, r.Cout, r.Cin, r.dw, r.inv_scale, r.db0, r.db1, r.inv_dev);
   return hipGetLastError();
 }
 
 template <typename T, int KS>
-static hipError_t launch_wg16_ks(const WgradArgs& a, hipStream_t s) {
+static hipError_t launch_wg16_ks(const WgradArgs& a, hipStream_t s, WgradReduce* red) {
   const bool wide = a.Cin > 32;
   static const bool wg_big = getenv("PU_WG_BIG") != nullptr, wg_4w = getenv("PU_WG_4W") != nullptr;     // diagnostic switches, read once
-  if (a.W % 32 == 0 && a.H % 8 == 0 && wide && wg_big) return launch_wg16<T, KS, 8, 32, 64>(a, s);   // 256-pixel K tiles: +4 % alone,
+  if (a.W % 32 == 0 && a.H % 8 == 0 && wide && wg_big) return launch_wg16<T, KS, 8, 32, 64>(a, s, red);   // 256-pixel K tiles: +4 % alone,
                                                                                             // but 152 KB LDS blocks co-residency with conv3
-  if (a.W % 32 == 0 && a.H % 4 == 0) return wide ? (wg_4w ? launch_wg16<T, KS, 4, 32, 64>(a, s) : launch_wg16<T, KS, 4, 32, 64, 8>(a, s)) : launch_wg16<T, KS, 4, 32, 32>(a, s);
-  if (a.W % 16 == 0 && a.H % 8 == 0) return wide ? launch_wg16<T, KS, 8, 16, 64>(a, s) : launch_wg16<T, KS, 8, 16, 32>(a, s);
-  if (a.W % 8 == 0 && a.H % 8 == 0) return wide ? launch_wg16<T, KS, 8, 8, 64>(a, s) : launch_wg16<T, KS, 8, 8, 32>(a, s);
+  if (a.W % 32 == 0 && a.H % 4 == 0) return wide ? (wg_4w ? launch_wg16<T, KS, 4, 32, 64>(a, s, red) : launch_wg16<T, KS, 4, 32, 64, 8>(a, s, red)) : launch_wg16<T, KS, 4, 32, 32>(a, s, red);
+  static const bool wg16_4w = getenv("PU_WG16_4W") != nullptr;
+  if (a.W % 16 == 0 && a.H % 8 == 0) return wide ? (wg16_4w ? launch_wg16<T, KS, 8, 16, 64>(a, s, red) : launch_wg16<T, KS, 8, 16, 64, 8>(a, s, red)) : launch_wg16<T, KS, 8, 16, 32>(a, s, red);
+  if (a.W % 8 == 0 && a.H % 8 == 0) return wide ? launch_wg16<T, KS, 8, 8, 64>(a, s, red) : launch_wg16<T, KS, 8, 8, 32>(a, s, red);
   return hipErrorInvalidValue;
 }
 
+// the split-K main kernel only; the caller runs launch_wgrad16_reduce(*red) afterwards (any stream ordered after `s`)
+template <typename T>
+hipError_t launch_wgrad16_main(const WgradArgs& a, hipStream_t s, WgradReduce* red) {
+  if (!a.slab || !red) return hipErrorInvalidValue;
+  if (a.taps == 9) return launch_wg16_ks<T, 3>(a, s, red);
+  if (a.taps == 1) return launch_wg16_ks<T, 1>(a, s, red);
+  return hipErrorInvalidValue;
+}
 template <typename T>
 hipError_t launch_wgrad16(const WgradArgs& a, hipStream_t s) {
-  if (!a.slab) return hipErrorInvalidValue;
-  if (a.taps == 9) return launch_wg16_ks<T, 3>(a, s);
-  if (a.taps == 1) return launch_wg16_ks<T, 1>(a, s);
-  return hipErrorInvalidValue;
+  WgradReduce r;
+  hipError_t e = launch_wgrad16_main<T>(a, s, &r);
+  return e != hipSuccess ? e : launch_wgrad16_reduce(r, s);
 }
 template hipError_t launch_wgrad16<f16>(const WgradArgs&, hipStream_t);
 template hipError_t launch_wgrad16<bf16>(const WgradArgs&, hipStream_t);
+template hipError_t launch_wgrad16_main<f16>(const WgradArgs&, hipStream_t, WgradReduce*);
+template hipError_t launch_wgrad16_main<bf16>(const WgradArgs&, hipStream_t, WgradReduce*);
 
 }  // namespace pu

@@ -39,7 +39,12 @@ struct PackDesc { long src_off; long dst_off; int Cout, Cin, taps, rows_pk, k_pk
 
 template <typename T> hipError_t launch_conv(const ConvArgs&, hipStream_t);
 template <typename T> hipError_t launch_wgrad(const WgradArgs&, hipStream_t);
-template <typename T> hipError_t launch_wgrad16(const WgradArgs&, hipStream_t);   // kernels_wgrad.hip (f16 / bf16)
+template <typename T> hipError_t launch_wgrad16(const WgradArgs&, hipStream_t);   // kernels_wgrad.hip (f16 / bf16): main + reduce on one stream
+// The two halves separately: the split-K main kernel fills `slab` and describes the pending fixed-order reduction, which may then
+// run on another stream (ordered after the main kernel) beside the NEXT weight gradient's main kernel.
+struct WgradReduce { const float* slab; int split, taps, cout_pad, cin_pad, Cout, Cin; float* dw; float inv_scale; float* db0; float* db1; const float* inv_dev; };
+template <typename T> hipError_t launch_wgrad16_main(const WgradArgs&, hipStream_t, WgradReduce* out);
+hipError_t launch_wgrad16_reduce(const WgradReduce&, hipStream_t);
 template <typename T> hipError_t launch_pack(const float* params, void* packed, const PackDesc* descs_dev, int ndesc, hipStream_t);
 
 // ---------------------------------------------------------------- layout / elementwise

@@ -8,7 +8,9 @@ lib = L.lib(); st = L.current_stream()
 SHAPES = [(32, 32, 256), (64, 64, 128), (128, 128, 64), (256, 256, 32), (512, 512, 16), (96, 32, 256), (192, 64, 128), (1024, 512, 16), (8, 32, 256)]
 dt = {"f16": 1, "bf16": 2, "f32": 0}[sys.argv[1] if len(sys.argv) > 1 else "f16"]
 B = 32
-only = sys.argv[2] if len(sys.argv) > 2 else None
+only = sys.argv[2] if len(sys.argv) > 2 and sys.argv[2] != "all" else None
+if len(sys.argv) > 3:                       # e.g. 256,256,32 : one shape only
+    SHAPES = [tuple(int(v) for v in sys.argv[3].split(","))]
 for mode, nm in ((0, "fwd"), (1, "dgrad"), (2, "wgrad")):
     if only and nm != only:
         continue
