@@ -87,16 +87,16 @@ struct pu_ctx {
   bool fused_stats = true;
   float wm_alpha = 0.007f, wm_beta = 0.048f, wm_lam = 0.f, wm_range = -1.f;     // wmse_ms_ssim_loss defaults (prob_unet.py:231-233)
   float* ms_ws = nullptr; size_t ms_ws_floats = 0;                              // MS-SSIM pyramid workspace, allocated on first use
-  // slab ring: the reduction of weight gradient k runs on `side3` beside the main kernel of weight gradient k + 1 (other slab)
-  static constexpr int NSLAB = 3;
-  hipStream_t side3 = nullptr; hipEvent_t slab_ev[NSLAB] = {nullptr, nullptr, nullptr}; bool slab_busy[NSLAB] = {false, false, false};
-  int slab_next = 0; bool side3_dirty = false;
+  // slab ring of two: weight gradient k + 1 writes one slab while its blocks first sum the slabs weight gradient k left in the other
+  // (WgradArgs::prev); the last pending reduction of a backward is flushed by the stand-alone kernel (flush_wgrad)
+  static constexpr int NSLAB = 2;
+  int slab_next = 0; bool wg_pending = false; WgradReduce wg_prev;
   hipStream_t side = nullptr, side2 = nullptr; std::vector<hipEvent_t> evs; size_t ev_next = 0; bool side_dirty = false; bool use_side = true;
   // injected dropout masks (parity tests): one site per UNetBlock in execution order
   struct DropSite { std::string name; int C, H, W; size_t off; };
   std::vector<DropSite> drop_sites; uint8_t* drop_masks = nullptr; size_t drop_masks_cap = 0; int drop_masks_B = 0;
   // data-parallel hand-off: flat gradient ranges in completion order + the events that mark them complete
-  struct Bucket { int64_t lo = 0, hi = 0; hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr}; bool rec[4] = {false, false, false, false}; };
+  struct Bucket { int64_t lo = 0, hi = 0; hipEvent_t ev[3] = {nullptr, nullptr, nullptr}; bool rec[3] = {false, false, false}; };
   int want_buckets = 0; std::vector<Bucket> buckets; std::vector<int64_t> cuts;      // cuts: descending flat offsets closing the U-Net buckets
   // cfg5: captured launch sequences of pu_sample / pu_sample_hr
   struct SampleGraph { std::vector<const void*> key; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
@@ -466,19 +466,22 @@ static int fork_side(pu_ctx* c, hipStream_t s, hipStream_t* out) {
   c->side_dirty = true; *out = c->side;
   return PU_OK;
 }
+// the last weight gradient of a chain has nobody after it to sum its slabs: stand-alone reduction kernel, on the stream the
+// weight gradients run on
+static int flush_wgrad(pu_ctx* c, hipStream_t s) {
+  if (!c->wg_pending) return PU_OK;
+  CKH(launch_wgrad16_reduce(c->wg_prev, (c->use_side && c->side_dirty) ? c->side : s));
+  c->wg_pending = false;
+  return PU_OK;
+}
 // join: `s` waits for the side stream (called once at the end of every backward)
 static int join_side(pu_ctx* c, hipStream_t s) {
+  { int r = flush_wgrad(c, s); if (r) return r; }
   if (!c->use_side || !c->side_dirty) return PU_OK;
   hipEvent_t e = c->evs[c->ev_next++ % c->evs.size()];
   CKH(hipEventRecord(e, c->side));
   CKH(hipStreamWaitEvent(s, e, 0));
   c->side_dirty = false;
-  if (c->side3_dirty) {
-    hipEvent_t e3 = c->evs[c->ev_next++ % c->evs.size()];
-    CKH(hipEventRecord(e3, c->side3));
-    CKH(hipStreamWaitEvent(s, e3, 0));
-    c->side3_dirty = false;
-  }
   return PU_OK;
 }
 // second side stream: the two latent encoders run beside the U-Net (forward and backward)
@@ -513,20 +516,14 @@ static int conv_wgrad(pu_ctx* c, const ConvL& L, TV dy, TV in, int B, hipStream_
   hipStream_t ws = s;
   if constexpr (sizeof(T) == 2) {
     int r = fork_side(c, s, &ws); if (r) return r;
-    if (ws != s && c->side3) {
-      // split-K main kernel on `side`, its fixed-order slab reduction on `side3`: the HBM-bound reduction of this weight gradient
-      // overlaps the MFMA-bound main kernel of the next one, which writes another slab of the ring
-      const int i = c->slab_next++ % pu_ctx::NSLAB;
-      a.slab = c->wg_slab + (size_t)i * c->wg_slab_floats;
-      if (c->slab_busy[i]) CKH(hipStreamWaitEvent(ws, c->slab_ev[i], 0));       // the reduction that last read this slab
-      WgradReduce red;
-      CKH(launch_wgrad16_main<T>(a, ws, &red));
-      hipEvent_t e = c->evs[c->ev_next++ % c->evs.size()];
-      CKH(hipEventRecord(e, ws));
-      CKH(hipStreamWaitEvent(c->side3, e, 0));
-      CKH(launch_wgrad16_reduce(red, c->side3));
-      CKH(hipEventRecord(c->slab_ev[i], c->side3));
-      c->slab_busy[i] = true; c->side3_dirty = true;
+    static const bool no_chain = getenv("PU_WG_NO_CHAIN") != nullptr;         // diagnostic: stand-alone reduction kernel per weight gradient
+    if (!no_chain) {
+      a.slab = c->wg_slab + (size_t)(c->slab_next++ % pu_ctx::NSLAB) * c->wg_slab_floats;
+      a.has_prev = c->wg_pending ? 1 : 0;
+      if (c->wg_pending) a.prev = c->wg_prev;
+      c->wg_pending = false;
+      CKH(launch_wgrad16_main<T>(a, ws, &c->wg_prev));
+      c->wg_pending = true;
       return PU_OK;
     }
   }
@@ -625,8 +622,8 @@ static void plan_buckets(pu_ctx* c) {
 static int record_bucket(pu_ctx* c, int k, hipStream_t s, hipStream_t s2 = nullptr) {
   if (k < 0 || k >= (int)c->buckets.size()) return PU_OK;
   pu_ctx::Bucket& q = c->buckets[k];
-  q.rec[0] = q.rec[1] = q.rec[2] = q.rec[3] = false;
-  if (c->use_side && c->side3_dirty && q.ev[3]) { CKH(hipEventRecord(q.ev[3], c->side3)); q.rec[3] = true; }
+  q.rec[0] = q.rec[1] = q.rec[2] = false;
+  { int r = flush_wgrad(c, s); if (r) return r; }          // the bucket's last weight gradient must not wait for a successor to sum its slabs
   if (q.ev[0]) { CKH(hipEventRecord(q.ev[0], s)); q.rec[0] = true; }
   if (c->use_side && c->side_dirty && q.ev[1]) { CKH(hipEventRecord(q.ev[1], c->side)); q.rec[1] = true; }
   if (s2 && s2 != s && q.ev[2]) { CKH(hipEventRecord(q.ev[2], s2)); q.rec[2] = true; }
@@ -820,8 +817,7 @@ int pu_create(const pu_config* cfg, int device, pu_ctx** out) {
   }
   if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) c->side = nullptr;
   if (hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking) != hipSuccess) c->side2 = nullptr;
-  if (getenv("PU_NO_REDUCE_STREAM") || hipStreamCreateWithFlags(&c->side3, hipStreamNonBlocking) != hipSuccess) c->side3 = nullptr;
-  if (c->side3) for (auto& e : c->slab_ev) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { e = nullptr; (void)hipStreamDestroy(c->side3); c->side3 = nullptr; break; }
+
   if (c->side) {
     c->evs.resize(256);
     for (auto& e : c->evs) if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { c->use_side = false; e = nullptr; }
@@ -841,8 +837,7 @@ int pu_destroy(pu_ctx* c) {
   for (auto e : c->evs) if (e) (void)hipEventDestroy(e);
   if (c->side) (void)hipStreamDestroy(c->side);
   if (c->side2) (void)hipStreamDestroy(c->side2);
-  if (c->side3) (void)hipStreamDestroy(c->side3);
-  for (auto e : c->slab_ev) if (e) (void)hipEventDestroy(e);
+
   if (c->ms_ws) (void)hipFree(c->ms_ws);
   if (c->arena) (void)(void)hipFree(c->arena);
   if (c->packed) (void)(void)hipFree(c->packed);
@@ -1254,7 +1249,7 @@ int pu_grad_bucket_wait(pu_ctx* c, int k, void* stream) {
   DeviceGuard dg(c->device);
   const auto& q = c->buckets[k];
   if (!q.rec[0]) FAIL(PU_ERR_STATE, "bucket %d has not been recorded: call pu_elbo_fwd_bwd(with_backward) first", k);
-  for (int i = 0; i < 4; ++i) if (q.rec[i]) CKH(hipStreamWaitEvent((hipStream_t)stream, q.ev[i], 0));
+  for (int i = 0; i < 3; ++i) if (q.rec[i]) CKH(hipStreamWaitEvent((hipStream_t)stream, q.ev[i], 0));
   return PU_OK;
 }
 int pu_nonfinite_flag(const float* g, int64_t n, float* flag, void* stream) {

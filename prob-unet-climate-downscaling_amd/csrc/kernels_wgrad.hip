@@ -42,9 +42,52 @@ __device__ __forceinline__ Frag tr_frag(const uint16_t* p0, const uint16_t* p1) 
   return u.f;
 }
 
-constexpr int WBCO = 64;
+// Pending reduction of the previous launch (WgradArgs::prev), slice `bid` of `nblk`: dw[co][ci][tap] += inv * sum_s slab[s][tap][co][ci]
+// in the fixed order s = 0, 1, ... (four interleaved partial sums, combined pairwise) -> bitwise reproducible.  The slab index space
+// [tap][cout_pad][cin_pad] is walked in float4 units (cin_pad is a multiple of 32), so every slab read is a coalesced 16-byte load.
+__device__ __forceinline__ void wgrad_reduce_slice(const WgradReduce& r, int bid, int nblk, int tid, int nth) {
+  float inv = r.inv_scale;
+  if (r.inv_dev) inv *= r.inv_dev[0];
+  const long per_tap = (long)r.cout_pad * r.cin_pad;
+  const long total4 = (long)r.taps * per_tap / 4;
+  const size_t stride = (size_t)r.taps * per_tap;
+  const long per_blk = (total4 + nblk - 1) / nblk;
+  const long j0 = (long)bid * per_blk, j1 = j0 + per_blk < total4 ? j0 + per_blk : total4;
+  for (long j = j0 + tid; j < j1; j += nth) {
+    const long e = j * 4;
+    const int ci = (int)(e % r.cin_pad);
+    const long q = e / r.cin_pad;
+    const int co = (int)(q % r.cout_pad), t = (int)(q / r.cout_pad);
+    if (co >= r.Cout || ci >= r.Cin) continue;
+    const float* p = r.slab + e;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    int k = 0;
+    for (; k + 3 < r.split; k += 4) {
+      const f32x4 v0 = *reinterpret_cast<const f32x4*>(p + (size_t)k * stride), v1 = *reinterpret_cast<const f32x4*>(p + (size_t)(k + 1) * stride);
+      const f32x4 v2 = *reinterpret_cast<const f32x4*>(p + (size_t)(k + 2) * stride), v3 = *reinterpret_cast<const f32x4*>(p + (size_t)(k + 3) * stride);
+      s0 += v0; s1 += v1; s2 += v2; s3 += v3;
+    }
+    for (; k < r.split; ++k) s0 += *reinterpret_cast<const f32x4*>(p + (size_t)k * stride);
+    const f32x4 sv = (s0 + s1) + (s2 + s3);
+    float* d = r.dw + ((size_t)co * r.Cin + ci) * r.taps + t;
+#pragma unroll
+    for (int e4 = 0; e4 < 4; ++e4)
+      if (ci + e4 < r.Cin) d[(size_t)e4 * r.taps] += sv[e4] * inv;
+  }
+  if (r.db0 && bid == nblk - 1) {                  // bias rows: slab tail [split][cout_pad]
+    const float* bs = r.slab + (size_t)r.split * stride;
+    for (int co = tid; co < r.Cout; co += nth) {
+      float sacc = 0.f;
+      for (int k = 0; k < r.split; ++k) sacc += bs[(size_t)k * r.cout_pad + co];
+      const float v = sacc * inv;
+      r.db0[co] += v;
+      if (r.db1) r.db1[co] += v;
+    }
+  }
+}
 
-template <typename T, int KS, int TH, int TW, int BCI, int NW>
+// BCO = couts per block (64, or 32 for the Cout <= 32 layers of the 256 x 256 level: half of a 64-cout tile would be zero padding)
+template <typename T, int KS, int TH, int TW, int BCI, int NW, int BCO>
 __global__ __launch_bounds__(64 * NW) void conv_wgrad16_kernel(WgradArgs a) {
   typedef MMW<T> M;
   constexpr int NTH = 64 * NW;
@@ -52,28 +95,32 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad16_kernel(WgradArgs a) {
   constexpr int BM = TH * TW;
   constexpr int IH = TH + 2 * PADP, IW = TW + 2 * PADP, NPH = IH * IW;
   constexpr int CIS = BCI / 32;                       // cin sub-tiles
-  constexpr int BUF = (2 * BM + CIS * NPH) * 32;      // elements per LDS buffer
-  constexpr int NVD_TOT = BM * 8, NVD = (NVD_TOT + NTH - 1) / NTH;   // 16-byte vectors of the dy tile per thread
+  constexpr int COS = BCO / 32;                       // cout sub-tiles
+  constexpr int BUF = (COS * BM + CIS * NPH) * 32;    // elements per LDS buffer
+  constexpr int NVD_TOT = BM * (BCO / 8), NVD = (NVD_TOT + NTH - 1) / NTH;   // 16-byte vectors of the dy tile per thread
   constexpr int NVA_TOT = NPH * (BCI / 8);
   constexpr int NVA = (NVA_TOT + NTH - 1) / NTH;
-  // wave roles: 4 waves, BCI == 64: (cout sub-tile, cin sub-tile) x all taps;  4 waves, BCI == 32: (cout sub-tile, tap half);
-  //             8 waves, BCI == 64: (cout sub-tile, cin sub-tile, tap half) - two waves per SIMD hide each other's LDS waits
-  constexpr bool SPLIT_TAPS = (BCI == 32) || (NW == 8);
-  constexpr int NJ = SPLIT_TAPS ? (TAPS + 1) / 2 : TAPS;
-  static_assert((NW == 4) || (NW == 8 && BCI == 64), "wave roles");
+  // wave roles: (cout sub-tile, cin sub-tile) x a tap group; the NW / (COS * CIS) tap groups split the taps evenly (two waves per
+  // SIMD hide each other's LDS waits in the 8-wave forms; a group beyond the last tap only helps with the staging loads)
+  constexpr int GROUPS = NW / (COS * CIS);
+  constexpr int NJ = (TAPS + GROUPS - 1) / GROUPS;
+  static_assert(NW % (COS * CIS) == 0 && GROUPS >= 1, "wave roles");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   uint16_t* lds = reinterpret_cast<uint16_t*>(smem_raw);
 
   const int tid = threadIdx.x, l = tid & 63, wave = tid >> 6;
-  const int ct = wave & 1;
-  const int it = BCI == 64 ? ((wave >> 1) & 1) : 0;
-  const int tap0 = !SPLIT_TAPS ? 0 : (BCI == 64 ? (wave >> 2) : (wave >> 1)) * NJ;
-  const int co0 = blockIdx.y * WBCO, ci0 = blockIdx.z * BCI;
+  const int ct = wave % COS;
+  const int it = (wave / COS) % CIS;
+  const int tap0 = (wave / (COS * CIS)) * NJ;
+  const int co0 = blockIdx.y * BCO, ci0 = blockIdx.z * BCI;
   const int tiles_x = a.W / TW, tiles_y = a.H / TH;
   const int ntiles = tiles_x * tiles_y * a.B;
   const uint16_t* dy = reinterpret_cast<const uint16_t*>(a.dy);
   const uint16_t* in = reinterpret_cast<const uint16_t*>(a.in);
+
+  if (a.has_prev)
+    wgrad_reduce_slice(a.prev, (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)), (int)(gridDim.x * gridDim.y * gridDim.z), tid, NTH);
 
   f32x16 acc[NJ];
 #pragma unroll
@@ -90,7 +137,7 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad16_kernel(WgradArgs a) {
 #pragma unroll
     for (int k = 0; k < NVD; ++k) {
       const int i = tid + k * NTH;
-      const int pix = (i >> 3) % BM, cv = i & 7;
+      const int pix = (i / (BCO / 8)) % BM, cv = i % (BCO / 8);
       const int gy = ty0 + pix / TW, gx = tx0 + pix % TW;
       const int co = co0 + cv * 8;
       rd[k] = zero16();
@@ -111,11 +158,11 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad16_kernel(WgradArgs a) {
   };
   auto lstore = [&](int buf) {
     uint16_t* sDy = lds + buf * BUF;
-    uint16_t* sA = sDy + 2 * BM * 32;
+    uint16_t* sA = sDy + COS * BM * 32;
 #pragma unroll
     for (int k = 0; k < NVD; ++k) {
       const int i = tid + k * NTH;
-      const int pix = i >> 3, cv = i & 7;
+      const int pix = i / (BCO / 8), cv = i % (BCO / 8);
       if (i < NVD_TOT) *reinterpret_cast<V16*>(sDy + ((cv >> 2) * BM + pix) * 32 + (cv & 3) * 8) = rd[k];
     }
 #pragma unroll
@@ -132,7 +179,8 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad16_kernel(WgradArgs a) {
   const int g = l >> 4, h = l >> 5, q = (l & 15) >> 2, p = l & 3;
   const int cb = 16 * (g & 1) + 4 * p;
 
-  // fused bias gradient (ci-tile 0 blocks): thread (co = tid & 63, quarter = tid >> 6) sums its pixels of every dy tile
+  // fused bias gradient (ci-tile 0 blocks): thread (co = tid % BCO, part = tid / BCO) sums its pixels of every dy tile
+  constexpr int BPARTS = NTH / BCO;
   const bool do_bias = a.dbias0 != nullptr && blockIdx.z == 0;
   float bsum = 0.f;
 
@@ -144,7 +192,7 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad16_kernel(WgradArgs a) {
     const int nxt = tile + gridDim.x;
     if (nxt < ntiles) gload(nxt);
     const uint16_t* sDy = lds + cur * BUF + (ct * BM) * 32 + cb;
-    const uint16_t* sA = lds + cur * BUF + 2 * BM * 32 + (it * NPH) * 32 + cb;
+    const uint16_t* sA = lds + cur * BUF + COS * BM * 32 + (it * NPH) * 32 + cb;
     // software-pipelined over the K-steps: the transposed reads of step kk+1 are issued as one block before the MFMAs of step
     // kk (sched_barrier keeps the blocks apart), so they land under those MFMAs instead of stalling their own consumers
     typename M::Frag fa[2], fb[2][NJ];
@@ -171,9 +219,10 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad16_kernel(WgradArgs a) {
       __builtin_amdgcn_sched_barrier(0);
     }
     if (do_bias) {
-      const uint16_t* col = lds + cur * BUF + (((tid & 63) >> 5) * BM) * 32 + (tid & 31);
+      const int bc = tid % BCO, bp = tid / BCO;
+      const uint16_t* col = lds + cur * BUF + ((bc >> 5) * BM) * 32 + (bc & 31);
 #pragma unroll 8
-      for (int pp = (tid >> 6) * (BM / NW); pp < ((tid >> 6) + 1) * (BM / NW); ++pp) {
+      for (int pp = bp * (BM / BPARTS); pp < (bp + 1) * (BM / BPARTS); ++pp) {
         T v; *reinterpret_cast<uint16_t*>(&v) = col[pp * 32];
         bsum += ET<T>::ld(&v);
       }
@@ -182,22 +231,22 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad16_kernel(WgradArgs a) {
     __syncthreads();
     cur ^= 1;
   }
-  if (do_bias) {                                  // combine the 4 pixel quarters, one partial row per split
+  if (do_bias) {                                  // combine the pixel parts, one partial row per split
     float* red = reinterpret_cast<float*>(smem_raw);
     red[tid] = bsum;
     __syncthreads();
-    if (tid < 64) {
-      const int cout_pad_b = gridDim.y * WBCO;
+    if (tid < BCO) {
+      const int cout_pad_b = gridDim.y * BCO;
       float* bslab = a.slab + (size_t)gridDim.x * TAPS * cout_pad_b * (gridDim.z * BCI) + (size_t)blockIdx.x * cout_pad_b;
       float sacc = 0.f;
 #pragma unroll
-      for (int w8 = 0; w8 < NW; ++w8) sacc += red[tid + 64 * w8];
+      for (int w8 = 0; w8 < BPARTS; ++w8) sacc += red[tid + BCO * w8];
       bslab[co0 + tid] = sacc;
     }
   }
 
   // ---- partial tile -> slab [split][tap][cout_pad][cin_pad] (cin contiguous: 128-byte coalesced rows)
-  const int cout_pad = gridDim.y * WBCO, cin_pad = gridDim.z * BCI;
+  const int cout_pad = gridDim.y * BCO, cin_pad = gridDim.z * BCI;
   float* slab = a.slab + (size_t)blockIdx.x * TAPS * cout_pad * cin_pad;
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
@@ -262,11 +311,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
-template <typename T, int KS, int TH, int TW, int BCI, int NW = 4>
+template <typename T, int KS, int TH, int TW, int BCI, int NW = 4, int WBCO = 64>
 static hipError_t launch_wg16(const WgradArgs& a, hipStream_t s, WgradReduce* red) {
   constexpr int PADP = KS / 2, BM = TH * TW, NPH = (TH + 2 * PADP) * (TW + 2 * PADP), TAPS = KS * KS;
-  constexpr size_t lds = (size_t)2 * (2 * BM + (BCI / 32) * NPH) * 32 * 2;
-  auto kern = conv_wgrad16_kernel<T, KS, TH, TW, BCI, NW>;
+  constexpr size_t lds_tiles = (size_t)2 * ((WBCO / 32) * BM + (BCI / 32) * NPH) * 32 * 2;
+  constexpr size_t lds = lds_tiles > (size_t)64 * NW * 4 ? lds_tiles : (size_t)64 * NW * 4;     // the bias combine reuses the buffer
+  auto kern = conv_wgrad16_kernel<T, KS, TH, TW, BCI, NW, WBCO>;
   static AttrOnce attr_once;
   if (!attr_once.cur()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -276,7 +326,7 @@ static hipError_t launch_wg16(const WgradArgs& a, hipStream_t s, WgradReduce* re
   const int ntiles = (a.W / TW) * (a.H / TH) * a.B;
   const int gy = cdiv(a.Cout, WBCO), gz = cdiv(a.Cin, BCI);
   const long per_split = (long)TAPS * gy * WBCO * gz * BCI + (long)gy * WBCO;   // + one bias row
-  int split = cdiv(BCI == 64 ? 256 : 512, gy * gz);      // resident blocks per CU: 1 (85 KB LDS) / 2 (59 KB); fewer, longer
+  int split = cdiv(lds > 80 * 1024 ? 256 : 512, gy * gz);   // resident blocks per CU: 1 (85 KB LDS) / 2 (<= 80 KB); fewer, longer
                                                          // K ranges keep the slab traffic (split x tile) below the operand traffic
   if (split > ntiles) split = ntiles;
   if ((long)split * per_split > a.slab_floats) split = (int)(a.slab_floats / per_split);
@@ -285,7 +335,7 @@ static hipError_t launch_wg16(const WgradArgs& a, hipStream_t s, WgradReduce* re
   char tag[128];
   const bool prof = prof_enabled();
   if (prof) {
-    snprintf(tag, sizeof tag, "conv_wgrad16_kernel<%s,%d,%d,%d,%d,%d>", ET<T>::DT == 1 ? "f16" : "bf16", KS, TH, TW, BCI, NW);
+    snprintf(tag, sizeof tag, "conv_wgrad16_kernel<%s,%d,%d,%d,%d,%d,%d>", ET<T>::DT == 1 ? "f16" : "bf16", KS, TH, TW, BCI, NW, WBCO);
     const double px = (double)a.B * a.H * a.W;
     prof_record(tag, 2.0 * px * a.Cout * (double)a.Cin * a.taps, px * (a.Cin + a.Cout) * 2 + (double)a.Cout * a.Cin * a.taps * 4, s, true);
   }
@@ -309,6 +359,9 @@ static hipError_t launch_wg16_ks(const WgradArgs& a, hipStream_t s, WgradReduce*
   static const bool wg_big = getenv("PU_WG_BIG") != nullptr, wg_4w = getenv("PU_WG_4W") != nullptr;     // diagnostic switches, read once
   if (a.W % 32 == 0 && a.H % 8 == 0 && wide && wg_big) return launch_wg16<T, KS, 8, 32, 64>(a, s, red);   // 256-pixel K tiles: +4 % alone,
                                                                                             // but 152 KB LDS blocks co-residency with conv3
+  static const bool no_bco32 = getenv("PU_WG_NO_BCO32") != nullptr;
+  if (a.W % 32 == 0 && a.H % 4 == 0 && a.Cout <= 32 && !no_bco32)      // 256 x 256 level: no zero-padded cout half; (cin sub-tile) x tap groups
+    return wide ? launch_wg16<T, KS, 4, 32, 64, 4, 32>(a, s, red) : launch_wg16<T, KS, 4, 32, 32, 4, 32>(a, s, red);
   if (a.W % 32 == 0 && a.H % 4 == 0) return wide ? (wg_4w ? launch_wg16<T, KS, 4, 32, 64>(a, s, red) : launch_wg16<T, KS, 4, 32, 64, 8>(a, s, red)) : launch_wg16<T, KS, 4, 32, 32>(a, s, red);
   static const bool wg16_4w = getenv("PU_WG16_4W") != nullptr;
   if (a.W % 16 == 0 && a.H % 8 == 0) return wide ? (wg16_4w ? launch_wg16<T, KS, 8, 16, 64>(a, s, red) : launch_wg16<T, KS, 8, 16, 64, 8>(a, s, red)) : launch_wg16<T, KS, 8, 16, 32>(a, s, red);
