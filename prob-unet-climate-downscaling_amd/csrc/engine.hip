@@ -87,10 +87,7 @@ struct pu_ctx {
   bool fused_stats = true;
   float wm_alpha = 0.007f, wm_beta = 0.048f, wm_lam = 0.f, wm_range = -1.f;     // wmse_ms_ssim_loss defaults (prob_unet.py:231-233)
   float* ms_ws = nullptr; size_t ms_ws_floats = 0;                              // MS-SSIM pyramid workspace, allocated on first use
-  // slab ring of two: weight gradient k + 1 writes one slab while its blocks first sum the slabs weight gradient k left in the other
-  // (WgradArgs::prev); the last pending reduction of a backward is flushed by the stand-alone kernel (flush_wgrad)
-  static constexpr int NSLAB = 2;
-  int slab_next = 0; bool wg_pending = false; WgradReduce wg_prev;
+  static constexpr int NSLAB = 1;
   hipStream_t side = nullptr, side2 = nullptr; std::vector<hipEvent_t> evs; size_t ev_next = 0; bool side_dirty = false; bool use_side = true;
   // injected dropout masks (parity tests): one site per UNetBlock in execution order
   struct DropSite { std::string name; int C, H, W; size_t off; };
@@ -466,17 +463,8 @@ static int fork_side(pu_ctx* c, hipStream_t s, hipStream_t* out) {
   c->side_dirty = true; *out = c->side;
   return PU_OK;
 }
-// the last weight gradient of a chain has nobody after it to sum its slabs: stand-alone reduction kernel, on the stream the
-// weight gradients run on
-static int flush_wgrad(pu_ctx* c, hipStream_t s) {
-  if (!c->wg_pending) return PU_OK;
-  CKH(launch_wgrad16_reduce(c->wg_prev, (c->use_side && c->side_dirty) ? c->side : s));
-  c->wg_pending = false;
-  return PU_OK;
-}
 // join: `s` waits for the side stream (called once at the end of every backward)
 static int join_side(pu_ctx* c, hipStream_t s) {
-  { int r = flush_wgrad(c, s); if (r) return r; }
   if (!c->use_side || !c->side_dirty) return PU_OK;
   hipEvent_t e = c->evs[c->ev_next++ % c->evs.size()];
   CKH(hipEventRecord(e, c->side));
@@ -516,16 +504,8 @@ static int conv_wgrad(pu_ctx* c, const ConvL& L, TV dy, TV in, int B, hipStream_
   hipStream_t ws = s;
   if constexpr (sizeof(T) == 2) {
     int r = fork_side(c, s, &ws); if (r) return r;
-    static const bool no_chain = getenv("PU_WG_NO_CHAIN") != nullptr;         // diagnostic: stand-alone reduction kernel per weight gradient
-    if (!no_chain) {
-      a.slab = c->wg_slab + (size_t)(c->slab_next++ % pu_ctx::NSLAB) * c->wg_slab_floats;
-      a.has_prev = c->wg_pending ? 1 : 0;
-      if (c->wg_pending) a.prev = c->wg_prev;
-      c->wg_pending = false;
-      CKH(launch_wgrad16_main<T>(a, ws, &c->wg_prev));
-      c->wg_pending = true;
-      return PU_OK;
-    }
+    // (chaining the slab reduction of weight gradient k into the prologue of weight gradient k + 1 - no stand-alone reduce kernel -
+    //  was measured and rejected: the HBM-latency-bound prologue delays every main kernel, 40.7 vs 37.4 ms per step)
   }
   CKH(launch_wgrad<T>(a, ws));
   return PU_OK;
@@ -623,7 +603,6 @@ static int record_bucket(pu_ctx* c, int k, hipStream_t s, hipStream_t s2 = nullp
   if (k < 0 || k >= (int)c->buckets.size()) return PU_OK;
   pu_ctx::Bucket& q = c->buckets[k];
   q.rec[0] = q.rec[1] = q.rec[2] = false;
-  { int r = flush_wgrad(c, s); if (r) return r; }          // the bucket's last weight gradient must not wait for a successor to sum its slabs
   if (q.ev[0]) { CKH(hipEventRecord(q.ev[0], s)); q.rec[0] = true; }
   if (c->use_side && c->side_dirty && q.ev[1]) { CKH(hipEventRecord(q.ev[1], c->side)); q.rec[1] = true; }
   if (s2 && s2 != s && q.ev[2]) { CKH(hipEventRecord(q.ev[2], s2)); q.rec[2] = true; }

@@ -42,50 +42,6 @@ __device__ __forceinline__ Frag tr_frag(const uint16_t* p0, const uint16_t* p1) 
   return u.f;
 }
 
-// Pending reduction of the previous launch (WgradArgs::prev), slice `bid` of `nblk`: dw[co][ci][tap] += inv * sum_s slab[s][tap][co][ci]
-// in the fixed order s = 0, 1, ... (four interleaved partial sums, combined pairwise) -> bitwise reproducible.  The slab index space
-// [tap][cout_pad][cin_pad] is walked in float4 units (cin_pad is a multiple of 32), so every slab read is a coalesced 16-byte load.
-__device__ __forceinline__ void wgrad_reduce_slice(const WgradReduce& r, int bid, int nblk, int tid, int nth) {
-  float inv = r.inv_scale;
-  if (r.inv_dev) inv *= r.inv_dev[0];
-  const long per_tap = (long)r.cout_pad * r.cin_pad;
-  const long total4 = (long)r.taps * per_tap / 4;
-  const size_t stride = (size_t)r.taps * per_tap;
-  const long per_blk = (total4 + nblk - 1) / nblk;
-  const long j0 = (long)bid * per_blk, j1 = j0 + per_blk < total4 ? j0 + per_blk : total4;
-  for (long j = j0 + tid; j < j1; j += nth) {
-    const long e = j * 4;
-    const int ci = (int)(e % r.cin_pad);
-    const long q = e / r.cin_pad;
-    const int co = (int)(q % r.cout_pad), t = (int)(q / r.cout_pad);
-    if (co >= r.Cout || ci >= r.Cin) continue;
-    const float* p = r.slab + e;
-    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
-    int k = 0;
-    for (; k + 3 < r.split; k += 4) {
-      const f32x4 v0 = *reinterpret_cast<const f32x4*>(p + (size_t)k * stride), v1 = *reinterpret_cast<const f32x4*>(p + (size_t)(k + 1) * stride);
-      const f32x4 v2 = *reinterpret_cast<const f32x4*>(p + (size_t)(k + 2) * stride), v3 = *reinterpret_cast<const f32x4*>(p + (size_t)(k + 3) * stride);
-      s0 += v0; s1 += v1; s2 += v2; s3 += v3;
-    }
-    for (; k < r.split; ++k) s0 += *reinterpret_cast<const f32x4*>(p + (size_t)k * stride);
-    const f32x4 sv = (s0 + s1) + (s2 + s3);
-    float* d = r.dw + ((size_t)co * r.Cin + ci) * r.taps + t;
-#pragma unroll
-    for (int e4 = 0; e4 < 4; ++e4)
-      if (ci + e4 < r.Cin) d[(size_t)e4 * r.taps] += sv[e4] * inv;
-  }
-  if (r.db0 && bid == nblk - 1) {                  // bias rows: slab tail [split][cout_pad]
-    const float* bs = r.slab + (size_t)r.split * stride;
-    for (int co = tid; co < r.Cout; co += nth) {
-      float sacc = 0.f;
-      for (int k = 0; k < r.split; ++k) sacc += bs[(size_t)k * r.cout_pad + co];
-      const float v = sacc * inv;
-      r.db0[co] += v;
-      if (r.db1) r.db1[co] += v;
-    }
-  }
-}
-
 // BCO = couts per block (64, or 32 for the Cout <= 32 layers of the 256 x 256 level: half of a 64-cout tile would be zero padding)
 template <typename T, int KS, int TH, int TW, int BCI, int NW, int BCO>
 __global__ __launch_bounds__(64 * NW) void conv_wgrad16_kernel(WgradArgs a) {
@@ -118,9 +74,6 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad16_kernel(WgradArgs a) {
   const int ntiles = tiles_x * tiles_y * a.B;
   const uint16_t* dy = reinterpret_cast<const uint16_t*>(a.dy);
   const uint16_t* in = reinterpret_cast<const uint16_t*>(a.in);
-
-  if (a.has_prev)
-    wgrad_reduce_slice(a.prev, (int)(blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)), (int)(gridDim.x * gridDim.y * gridDim.z), tid, NTH);
 
   f32x16 acc[NJ];
 #pragma unroll

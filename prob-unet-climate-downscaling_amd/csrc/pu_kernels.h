@@ -36,18 +36,13 @@ struct WgradArgs {
   float inv_scale;                               // parameter gradients are multiplied by this (loss-scale removal)
   const float* inv_scale_dev;                    // optional device float multiplied on top (sub-graph scale chosen on the device)
   float* dbias0; float* dbias1;                  // optional (16-bit path): bias gradient(s) = column sums of dy, ADDED into
-  // 16-bit path: the pending reduction of the PREVIOUS weight gradient (it wrote the other slab of the ring) is carried out by
-  // the blocks of this launch before their own K loop - each block sums a 1 / nblocks slice - so that no separate reduction kernel
-  // (and no kernel boundary) is needed between two weight gradients.  has_prev == 0: nothing pending.
-  WgradReduce prev; int has_prev;
 };
 struct PackDesc { long src_off; long dst_off; int Cout, Cin, taps, rows_pk, k_pk, mode; };   // mode: 0 fwd, 1 dgrad; +2 = fragment-major
 
 template <typename T> hipError_t launch_conv(const ConvArgs&, hipStream_t);
 template <typename T> hipError_t launch_wgrad(const WgradArgs&, hipStream_t);
 template <typename T> hipError_t launch_wgrad16(const WgradArgs&, hipStream_t);   // kernels_wgrad.hip (f16 / bf16): main + reduce on one stream
-// The two halves separately: the split-K main kernel fills `slab` and describes the pending fixed-order reduction, which the caller
-// hands to the NEXT weight gradient (WgradArgs::prev) or flushes with the stand-alone reduction kernel.
+// The two halves separately: the split-K main kernel fills `slab` and describes the pending fixed-order reduction.
 template <typename T> hipError_t launch_wgrad16_main(const WgradArgs&, hipStream_t, WgradReduce* out);
 hipError_t launch_wgrad16_reduce(const WgradReduce&, hipStream_t);
 template <typename T> hipError_t launch_pack(const float* params, void* packed, const PackDesc* descs_dev, int ndesc, hipStream_t);
