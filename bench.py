@@ -149,7 +149,7 @@ def bench_sample(args, steps=None, warmup=None, inputs=None, graph=True):
     torch.cuda.set_device(0)
     steps = args.steps if steps is None else steps
     warmup = max(3, args.warmup if warmup is None else warmup)       # call 1 eager, call 2 captures, call 3+ replay
-    B = inputs if inputs is not None else (args.batch if args.mode == "sample" and args.batch != CFG3["batch"] else 32)
+    B = inputs if inputs is not None else (args.batch if args.mode == "sample" and args.batch != CFG3["batch"] else 64)
     cfg = dict(CFG3, batch=B, M=args.samples)
     model = build_model(cfg, args.dtype, device).eval()
     model.use_sample_graph = graph

@@ -106,6 +106,11 @@ constexpr int KC = 32;     // channels staged per K chunk
 #ifndef PU_ABLATE
 #define PU_ABLATE 0
 #endif
+// Experimental variants of conv3_kernel (A/B builds through tools/ablate_conv.sh with VARIANT=<bits>): 1 = LDS fragment reads two
+// groups ahead (three register buffers), 2 = the two co-resident blocks of a CU alternate s_setprio per chunk (fair MFMA arbitration)
+#ifndef PU_VARIANT
+#define PU_VARIANT 0
+#endif
 
 // ------------------------------------------------------------------ forward / dgrad implicit GEMM
 // Block = 64*WM*WN threads; pixel tile TH x TW (BM = TH*TW pixels, BM/WM per wave in 32-pixel MFMA columns);
@@ -388,19 +393,25 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3_kernel(ConvArgs a) {
     }
   }
   V16 ri[NVI];
-  // branch-free staging loads: out-of-image / beyond-Cin vectors read a valid dummy address and are zeroed by a select,
-  // so the whole chunk body stays one basic block (the scheduler can then run LDS reads ahead of the MFMAs)
+  // branch-free staging loads: out-of-image / beyond-Cin vectors read a valid dummy address and are zeroed by a select, so the
+  // whole chunk body stays one basic block.  The select is applied when the vector is WRITTEN to LDS (end of the chunk), not
+  // where it is loaded: a select next to the load made every chunk start with s_waitcnt vmcnt(0) - the halo loads AND the 18
+  // weight-fragment loads in flight drained before the first MFMA of the chunk (half of a wave's cycles).
+  auto gok = [&](int k, int c0) -> bool { return gi[k] >= 0 && c0 + (li[k] % KCP) < a.Cin; };
   auto gload = [&](int c0) {
 #pragma unroll
-    for (int k = 0; k < NVI; ++k) {
-      const bool ok = gi[k] >= 0 && c0 + (li[k] % KCP) < a.Cin;
-      const V16 v = *reinterpret_cast<const V16*>(in + (ok ? (size_t)(unsigned)gi[k] + c0 : (size_t)0));
-      ri[k].w[0] = ok ? v.w[0] : 0u; ri[k].w[1] = ok ? v.w[1] : 0u; ri[k].w[2] = ok ? v.w[2] : 0u; ri[k].w[3] = ok ? v.w[3] : 0u;
-    }
+    for (int k = 0; k < NVI; ++k)
+      ri[k] = *reinterpret_cast<const V16*>(in + (gok(k, c0) ? (size_t)(unsigned)gi[k] + c0 : (size_t)0));
   };
-  auto lstore = [&](int buf) {
+  auto lstore = [&](int buf, int c0) {
 #pragma unroll
-    for (int k = 0; k < NVI; ++k) if (li[k] >= 0) *reinterpret_cast<V16*>(sIn + buf * BUF + li[k]) = ri[k];
+    for (int k = 0; k < NVI; ++k)
+      if (li[k] >= 0) {
+        const bool ok = gok(k, c0);
+        V16 v;
+        v.w[0] = ok ? ri[k].w[0] : 0u; v.w[1] = ok ? ri[k].w[1] : 0u; v.w[2] = ok ? ri[k].w[2] : 0u; v.w[3] = ok ? ri[k].w[3] : 0u;
+        *reinterpret_cast<V16*>(sIn + buf * BUF + li[k]) = v;
+      }
   };
   typename M::Frag fa[TAPS][2];
   const T* wbase = have_w ? wfrag : reinterpret_cast<const T*>(a.wpk) + l * 8;     // idle waves read tile 0 (never stored)
@@ -418,21 +429,56 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3_kernel(ConvArgs a) {
   }
 
   gload(0);
+  // the prologue issues the weight-fragment loads in EXACTLY the order the loop re-issues them (sched_barrier pins it): the
+  // compiler merges the vmcnt distances of the loop's two entry paths conservatively, and a reordered prologue turned one of the
+  // loop's waits into a near-drain of the load queue (vmcnt(9) where 21 loads may stay in flight) on every chunk
 #pragma unroll
-  for (int t = 0; t < TAPS; ++t) { fa[t][0] = wload(0, t, 0); fa[t][1] = wload(0, t, 1); }
-  lstore(0);
+  for (int t = 0; t < TAPS; ++t) {
+    fa[t][0] = wload(0, t, 0); __builtin_amdgcn_sched_barrier(0);
+    fa[t][1] = wload(0, t, 1); __builtin_amdgcn_sched_barrier(0);
+  }
+  lstore(0, 0);
   __syncthreads();
 #if PU_ABLATE & 32
   ts1 = __builtin_amdgcn_s_memtime();
 #endif
+#if PU_VARIANT & 2
+  // the block that was dispatched second onto this CU has a non-zero LDS base: it is the younger wave on every SIMD and loses the
+  // age-ordered MFMA arbitration; the two blocks take turns at priority 1, one chunk each
+  const int young = (__builtin_amdgcn_s_getreg((7 << 11) | (0 << 6) | 6) & 0xff) != 0 ? 1 : 0;
+#endif
   int cur = 0;
   for (int c = 0; c < nch; ++c) {
+#if PU_VARIANT & 2
+    if ((c ^ young) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+#endif
     const bool more = c + 1 < nch;
     const int cn = more ? c + 1 : c;               // the last chunk harmlessly re-reads its own fragments
-    if (more && !(PU_ABLATE & 2)) gload((c + 1) * KC);
+    if (!(PU_ABLATE & 2)) gload(cn * KC);          // unconditional (the last chunk re-reads itself): the chunk body stays ONE basic
+                                                   // block, so the compiler's s_waitcnt vmcnt counts are exact across the back-edge
     const T* sb = sIn + cur * BUF;
     // software-pipelined over the 2*TAPS (tap, k-step) groups: the NTM LDS fragment reads of group g+1 are issued between
     // the MFMAs of group g (one ds_read_b128 per MFMA slot), so no MFMA waits on a read issued right before it
+#if PU_VARIANT & 1
+    typename M::Frag fb[3][NTM];
+    auto fb_read = [&](int g, int slot) {
+      const int t1 = g >> 1, kk1 = g & 1;
+      const int toff1 = ((t1 / KS) * IW + (t1 % KS)) * KCP + kk1 * 16;
+#pragma unroll
+      for (int j = 0; j < NTM; ++j) fb[slot][j] = *reinterpret_cast<const typename M::Frag*>(sb + pbase[j] + toff1);
+    };
+    fb_read(0, 0); fb_read(1, 1);
+#pragma unroll
+    for (int g = 0; g < 2 * TAPS; ++g) {
+      const int t = g >> 1, kk = g & 1;
+      if (g + 2 < 2 * TAPS) fb_read(g + 2, (g + 2) % 3);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < NTM; ++j) acc[j] = M::mfma(fa[t][kk], fb[g % 3][j], acc[j]);
+      fa[t][kk] = wload(cn, t, kk);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#else
     typename M::Frag fb[2][NTM];
 #pragma unroll
     for (int j = 0; j < NTM; ++j) fb[0][j] = *reinterpret_cast<const typename M::Frag*>(sb + pbase[j]);
@@ -456,7 +502,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3_kernel(ConvArgs a) {
       __builtin_amdgcn_sched_barrier(0);           // keep [reads of g+1 | MFMAs of g | weight refill] as issued: the reads land
                                                    // under the 8 MFMAs instead of being sunk next to their consumers
     }
-    if (more && !(PU_ABLATE & 2)) lstore(cur ^ 1);
+#endif
+    if (more && !(PU_ABLATE & 2)) lstore(cur ^ 1, (c + 1) * KC);
     if (!(PU_ABLATE & 4)) __syncthreads();
     if (!(PU_ABLATE & 2)) cur ^= 1;
   }
@@ -533,8 +580,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3_kernel(ConvArgs a) {
 #if PU_ABLATE & 32
   {
     const uint64_t ts3 = __builtin_amdgcn_s_memtime(), tr3 = __builtin_amdgcn_s_memrealtime();
-    if (l == 0 && (blockIdx.x % 97) == 0 && blockIdx.y == 0 && wave == 0)
-      printf("blk %4d nch %2d: prologue %6llu loop %7llu (%6llu per chunk) epilogue %6llu cycles; clock %.3f GHz\n", (int)blockIdx.x, nch,
+    const unsigned hwid = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4), xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);
+    if (l == 0 && wave == 0 && (((blockIdx.x + 7 * blockIdx.y) % 13) == 0))
+      printf("blk %4d,%d xcc %u se %u cu %2u simd %u | start %8llu end %8llu (x10ns) | prologue %6llu loop %7llu (%5llu/chunk) epilogue %6llu cyc | %.3f GHz\n",
+             (int)blockIdx.x, (int)blockIdx.y, xcc & 15u, (hwid >> 13) & 7u, (hwid >> 8) & 15u, (hwid >> 4) & 3u,
+             (unsigned long long)(tr0 % 100000000ull), (unsigned long long)(tr3 % 100000000ull),
              (unsigned long long)(ts1 - ts0), (unsigned long long)(ts2 - ts1), (unsigned long long)((ts2 - ts1) / nch), (unsigned long long)(ts3 - ts2),
              (double)(ts3 - ts0) / (double)(tr3 - tr0) * 0.1);
   }

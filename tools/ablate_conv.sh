@@ -8,14 +8,14 @@ BITS="${ABLATE_BITS:-32 47 63}"
 if [ "$1" != "run" ]; then
   make -C $C -j8 > /dev/null
   for b in $BITS; do
-    $HIPCC --offload-arch=gfx950 -O3 -fPIC -std=c++17 -DPU_ABLATE=$b -c $C/kernels_conv.hip -o $C/build/kernels_conv_ab$b.o &
+    $HIPCC --offload-arch=gfx950 -O3 -fPIC -std=c++17 -DPU_ABLATE=$b -DPU_VARIANT=${VARIANT:-0} -c $C/kernels_conv.hip -o $C/build/kernels_conv_ab${b}v${VARIANT:-0}.o &
   done; wait
   for b in $BITS; do
-    $HIPCC --offload-arch=gfx950 -shared -fPIC -o $R/prob-unet-climate-downscaling_amd/libprobunet_ab$b.so $C/build/engine.o $C/build/kernels_conv_ab$b.o \
+    $HIPCC --offload-arch=gfx950 -shared -fPIC -o $R/prob-unet-climate-downscaling_amd/libprobunet_ab${b}v${VARIANT:-0}.so $C/build/engine.o $C/build/kernels_conv_ab${b}v${VARIANT:-0}.o \
       $C/build/kernels_wgrad.o $C/build/kernels_elem.o $C/build/kernels_fcomb.o $C/build/kernels_msssim.o
   done
   ls -la $R/prob-unet-climate-downscaling_amd/*.so
 else
   echo "== baseline"; python3 $R/tools/conv_microbench.py f16 fwd
-  for b in $BITS; do echo "== ablate $b"; PU_LIB_PATH=$R/prob-unet-climate-downscaling_amd/libprobunet_ab$b.so python3 $R/tools/conv_microbench.py f16 fwd; done
+  for b in $BITS; do echo "== ablate $b"; PU_LIB_PATH=$R/prob-unet-climate-downscaling_amd/libprobunet_ab${b}v${VARIANT:-0}.so python3 $R/tools/conv_microbench.py f16 fwd; done
 fi
