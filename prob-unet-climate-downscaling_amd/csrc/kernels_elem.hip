@@ -150,15 +150,17 @@ __global__ __launch_bounds__(256) void chan_partial_kernel(TV x, float* __restri
   }
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void gn_finalize_kernel(TV x, const float* __restrict__ part, int nchunk, int G, float eps,
+// NT threads per block (one block per sample): the per-channel sums over the producer's statistics rows are shared by NT / C
+// threads - with 256 threads a 32-channel tensor of the 256 x 256 level left each thread a chain of 128 dependent row loads
+template <typename T, int NT>
+__global__ __launch_bounds__(NT) void gn_finalize_kernel(TV x, const float* __restrict__ part, int nchunk, int G, float eps,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           const float* __restrict__ scale, const float* __restrict__ shift,
                                                           float* __restrict__ stat, float* __restrict__ coef,
                                                           const float* __restrict__ ps0, int ns0, int pc0,
                                                           const float* __restrict__ ps1, int ns1) {
   __shared__ double cs[1024 * 2];      // per channel: mean_c, M2_c
-  __shared__ double red[256 * 2];
+  __shared__ double red[NT * 2];
   __shared__ float gs[64];
   const int b = blockIdx.x, tid = threadIdx.x, C = x.C;
   const long HW = (long)x.H * x.W;
@@ -168,8 +170,8 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(TV x, const float* __r
       const float* ps = src ? ps1 : ps0;
       const int Cs = src ? C - pc0 : pc0, cb = src ? pc0 : 0, ns = src ? ns1 : ns0;
       if (Cs <= 0) continue;
-      const int nl = Cs >= 256 ? 1 : 256 / Cs;
-      for (int c0 = 0; c0 < Cs; c0 += 256) {
+      const int nl = Cs >= NT ? 1 : NT / Cs;
+      for (int c0 = 0; c0 < Cs; c0 += NT) {
         const int c = nl > 1 ? tid % Cs : c0 + tid, lane = nl > 1 ? tid / Cs : 0;
         double a = 0, q = 0;
         if (c < Cs && lane < nl) {
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(TV x, const float* __r
     }
   } else {
     const T* x0 = reinterpret_cast<const T*>(x.p) + (long)b * HW * x.ld;      // first pixel of the sample = the shift
-    for (int c = tid; c < C; c += 256) {
+    for (int c = tid; c < C; c += NT) {
       double a = 0, q = 0;
       for (int k = 0; k < nchunk; ++k) { const float* pp = part + (((long)b * nchunk + k) * C + c) * 2; a += pp[0]; q += pp[1]; }
       const double n = (double)HW, sh = (double)ET<T>::ld(x0 + c);
@@ -219,7 +221,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(TV x, const float* __r
   }
   __syncthreads();
   // y = A (x - mean_g) + Bp   (the mean is subtracted from x before scaling: no cancellation against a folded offset)
-  for (int c = tid; c < C; c += 256) {
+  for (int c = tid; c < C; c += NT) {
     const int g = c / cpg;
     const float rstd = gs[g * 2 + 1];
     const float sc = scale ? scale[c] : 0.f, t = shift ? shift[c] : 0.f;
@@ -351,7 +353,7 @@ hipError_t launch_gn_fwd(const GNArgs& a0, hipStream_t s) {
     const GNArgs a = gn_sub(a0, b0, nb, sizeof(T));
     const bool fused = a.ps0 && a.ns0 > 0 && (a.pc0 >= a.x.C || (a.ps1 && a.ns1 > 0)) && step == a0.x.B;
     if (!fused) hipLaunchKernelGGL((chan_partial_kernel<T, true>), dim3(a.nchunk, a.x.B), dim3(256), 0, s, a.x, a.part, a.nchunk, 1);
-    hipLaunchKernelGGL(gn_finalize_kernel<T>, dim3(a.x.B), dim3(256), 0, s, a.x, a.part, a.nchunk, a.G, a.eps, a.gamma, a.beta,
+    hipLaunchKernelGGL((gn_finalize_kernel<T, 1024>), dim3(a.x.B), dim3(1024), 0, s, a.x, a.part, a.nchunk, a.G, a.eps, a.gamma, a.beta,
                        a.scale, a.shift, a.stat, a.coef, fused ? a.ps0 : nullptr, a.ns0, a.pc0, a.ps1, a.ns1);
     (void)HW;
     const dim3 ga(gn_pix_blocks((long)a.y.H * a.y.W, a.x.C / ET<T>::VEC, a.x.B), a.x.B);
@@ -484,7 +486,8 @@ __global__ __launch_bounds__(256) void gn_bwd_pass1_kernel(GNBwdArgs a) {
   }
 }
 
-__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(GNBwdArgs a) {
+template <int NT>
+__global__ __launch_bounds__(NT) void gn_bwd_finalize_kernel(GNBwdArgs a) {
   __shared__ float cs[1024 * 2];
   __shared__ float gm[64];
   const GNArgs& f = a.f;
@@ -493,11 +496,11 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(GNBwdArgs a) {
   {
     // per-channel totals of the pass-1 rows: nl threads share a channel (with C = 32 a one-thread-per-channel loop would
     // leave 224 of the block's 256 threads idle behind 64 dependent loads)
-    __shared__ float red[256 * 2];
+    __shared__ float red[NT * 2];
     const float2* part = reinterpret_cast<const float2*>(a.part2);
     const int nk = f.nchunk;
-    const int nl = C >= 256 ? 1 : 256 / C;
-    for (int c0 = 0; c0 < C; c0 += 256) {
+    const int nl = C >= NT ? 1 : NT / C;
+    for (int c0 = 0; c0 < C; c0 += NT) {
       const int c = nl > 1 ? tid % C : c0 + tid, lane = nl > 1 ? tid / C : 0;
       float u = 0.f, w = 0.f;
       if (c < C && lane < nl) {
@@ -523,7 +526,7 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(GNBwdArgs a) {
     gm[tid * 2] = m1 / n; gm[tid * 2 + 1] = m2 / n;
   }
   __syncthreads();
-  for (int c = tid; c < C; c += 256) {
+  for (int c = tid; c < C; c += NT) {
     const int g = c / cpg;
     const float mean = f.stat[((long)b * G + g) * 2], rstd = f.stat[((long)b * G + g) * 2 + 1];
     const float gp = f.gamma[c] * (1.f + (f.scale ? f.scale[c] : 0.f));
@@ -768,7 +771,7 @@ hipError_t launch_gn_bwd(const GNBwdArgs& a0, hipStream_t s) {
     if (f.resample == RS_NONE) hipLaunchKernelGGL((gn_bwd_pass1_kernel<T, RS_NONE>), g1, dim3(256), 0, s, a);
     else if (f.resample == RS_DOWN) hipLaunchKernelGGL((gn_bwd_pass1_kernel<T, RS_DOWN>), g1, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((gn_bwd_pass1_kernel<T, RS_UP>), g1, dim3(256), 0, s, a);
-    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(f.x.B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel<1024>, dim3(f.x.B), dim3(1024), 0, s, a);
     const dim3 g2(gn_pix_blocks((long)f.x.H * f.x.W, f.x.C / ET<T>::VEC, f.x.B), f.x.B);
     if (f.resample == RS_NONE) hipLaunchKernelGGL((gn_bwd_pass2_kernel<T, RS_NONE>), g2, dim3(256), 0, s, a);
     else if (f.resample == RS_DOWN) hipLaunchKernelGGL((gn_bwd_pass2_kernel<T, RS_DOWN>), g2, dim3(256), 0, s, a);
