@@ -856,7 +856,11 @@ static hipError_t launch_conv3(const ConvArgs& a, hipStream_t s) {
   if constexpr (sizeof(T) == 2) {
     // 64 -> 64-class layers: the non-persistent kernel on 128-pixel tiles keeps ~4 blocks per CU resident and beats the
     // 148 KB-LDS persistent configuration by ~7 %
-    if (a.cin_pk == 2 * KC && a.Cout > 32 && a.Cout <= 64 && a.W % 32 == 0 && a.H % 4 == 0)
+    static const int c64_mode = getenv("PU_C64_MODE") ? atoi(getenv("PU_C64_MODE")) : 1;     // 1 = 256-pixel tiles (default: one weight fragment
+                                                     // load per 4 MFMAs instead of per 2; +0.8 % per step), 0 = 128-pixel tiles, 2 = persistent conv3p
+    if (a.cin_pk == 2 * KC && a.Cout > 32 && a.Cout <= 64 && a.W % 32 == 0 && a.H % 8 == 0 && c64_mode == 1)
+      return launch_conv3_cfg<T, KS, 8, 32, 2, 2>(a, s);
+    if (a.cin_pk == 2 * KC && a.Cout > 32 && a.Cout <= 64 && a.W % 32 == 0 && a.H % 4 == 0 && c64_mode != 2)
       return launch_conv3_cfg<T, KS, 4, 32, 2, 2>(a, s);
     static const bool no_conv3p = getenv("PU_NO_CONV3P") != nullptr;       // diagnostic switch, read once
     if (a.cin_pk <= 2 * KC && !no_conv3p) {       // short-K layers: persistent, weight-resident variant
