@@ -27,6 +27,7 @@ struct ConvL {
   int cout_pk = 0, rows_bwd = 0;       // dgrad pack:   [rows_bwd][taps][cout_pk]
   bool need_dgrad = true;
   bool frag = false;                   // packed weights are fragment-major (conv3 kernel)
+  bool m16_fwd = false, m16_bwd = false;   // ... as v_mfma_f32_16x16x32 fragments (forward / data-gradient pack)
 };
 struct GNL {
   int C = 0, G = 0, nchunk = 1;
@@ -169,12 +170,15 @@ static void setup_conv(pu_ctx* c, ConvL& L, int cin, int cout, int ks, int64_t w
   const int taps = ks * ks;
   L.cin_pk = rup(cin, 32); L.rows_fwd = rup(cout, 32);
   L.pk_fwd = c->packed_elems; c->packed_elems += (long)L.rows_fwd * taps * L.cin_pk;
-  PackDesc d; d.src_off = w_off; d.dst_off = L.pk_fwd; d.Cout = cout; d.Cin = cin; d.taps = taps; d.rows_pk = L.rows_fwd; d.k_pk = L.cin_pk; d.mode = L.frag ? 2 : 0;
+  L.m16_fwd = L.frag && conv_uses_mfma16((int)c->esz, taps, L.cin_pk, cout, rh, rw);
+  PackDesc d; d.src_off = w_off; d.dst_off = L.pk_fwd; d.Cout = cout; d.Cin = cin; d.taps = taps; d.rows_pk = L.rows_fwd; d.k_pk = L.cin_pk;
+  d.mode = L.frag ? (L.m16_fwd ? 6 : 2) : 0;
   c->descs.push_back(d);
   if (need_dgrad) {
     L.cout_pk = rup(cout, 32); L.rows_bwd = rup(cin, 32);
     L.pk_bwd = c->packed_elems; c->packed_elems += (long)L.rows_bwd * taps * L.cout_pk;
-    d.dst_off = L.pk_bwd; d.rows_pk = L.rows_bwd; d.k_pk = L.cout_pk; d.mode = L.frag ? 3 : 1;
+    L.m16_bwd = L.frag && conv_uses_mfma16((int)c->esz, taps, L.cout_pk, rup(cin, 8), rh, rw);      // data gradient: K = cout, N = the stored cin planes
+    d.dst_off = L.pk_bwd; d.rows_pk = L.rows_bwd; d.k_pk = L.cout_pk; d.mode = L.frag ? (L.m16_bwd ? 7 : 3) : 1;
     c->descs.push_back(d);
   }
 }
@@ -435,6 +439,7 @@ static int conv_fwd(pu_ctx* c, const ConvL& L, TV in, TV out, int B, bool relu, 
   a.res = res ? res->p : nullptr; a.res_ld = res ? res->ld : 0;
   a.out = out.p; a.out_ld = out.ld; a.Cout = L.cout;
   a.B = B; a.H = out.H; a.W = out.W; a.relu = relu ? 1 : 0; a.accumulate = accumulate; a.frag_layout = L.frag ? 1 : 0;
+  a.mfma16 = L.m16_fwd ? 1 : 0;
   if (a.Cin > L.cin_pk) a.Cin = L.cin_pk;
   CKH(launch_conv<T>(a, s));
   return PU_OK;
@@ -450,6 +455,7 @@ static int conv_dgrad(pu_ctx* c, const ConvL& L, TV dy, TV dx, int B, int accumu
   a.Cout = dx.C;                      // write every allocated plane (planes >= L.cin receive zeros from zero-padded weights)
   if (a.Cout > L.rows_bwd) a.Cout = L.rows_bwd;
   a.B = B; a.H = dx.H; a.W = dx.W; a.relu = 0; a.accumulate = accumulate; a.frag_layout = L.frag ? 1 : 0;
+  a.mfma16 = L.m16_bwd ? 1 : 0;
   CKH(launch_conv<T>(a, s));
   return PU_OK;
 }
@@ -1321,25 +1327,29 @@ static int op_conv_t(int mode, int ks, int relu, int B, int Cin, int Cout, int H
   ty.p = yb; ty.B = B; ty.H = H; ty.W = W; ty.C = cout_a; ty.ld = cout_a;
   if (mode == 0) {
     d.rows_pk = rup(Cout, 32); d.k_pk = rup(Cin, 32); d.mode = conv_uses_frag_layout((int)esz, H, W) ? 2 : 0;
+    const bool m16 = d.mode == 2 && conv_uses_mfma16((int)esz, taps, d.k_pk, Cout, H, W);
+    if (m16) d.mode = 6;
     CK0(hipMalloc(&wp, (size_t)d.rows_pk * taps * d.k_pk * esz));
     CK0(hipMemcpyAsync(dd, &d, sizeof d, hipMemcpyHostToDevice, s));
     CK0(launch_pack<T>(w, wp, dd, 1, s));
     CK0(launch_nchw_to_nhwc<T>(x, (long)Cin * H * W, Cin, nullptr, 0, tx, s));
     ConvArgs a; memset(&a, 0, sizeof a);
     a.in = xin; a.in_ld = cin_a; a.Cin = cin_a; a.wpk = wp; a.cin_pk = d.k_pk; a.cout_pk = d.rows_pk; a.taps = taps; a.bias = bias;
-    a.out = yb; a.out_ld = cout_a; a.Cout = Cout; a.B = B; a.H = H; a.W = W; a.relu = relu; a.frag_layout = d.mode >= 2;
+    a.out = yb; a.out_ld = cout_a; a.Cout = Cout; a.B = B; a.H = H; a.W = W; a.relu = relu; a.frag_layout = d.mode >= 2; a.mfma16 = m16;
     CK0(hipMemsetAsync(yb, 0, npix * cout_a * esz, s));
     CK0(launch_conv<T>(a, s));
     CK0(launch_nhwc_to_nchw<T>(ty, Cout, out, 0, s));
   } else if (mode == 1) {
     d.rows_pk = rup(Cin, 32); d.k_pk = rup(Cout, 32); d.mode = conv_uses_frag_layout((int)esz, H, W) ? 3 : 1;
+    const bool m16 = d.mode == 3 && conv_uses_mfma16((int)esz, taps, d.k_pk, cin_a, H, W);
+    if (m16) d.mode = 7;
     CK0(hipMalloc(&wp, (size_t)d.rows_pk * taps * d.k_pk * esz));
     CK0(hipMemcpyAsync(dd, &d, sizeof d, hipMemcpyHostToDevice, s));
     CK0(launch_pack<T>(w, wp, dd, 1, s));
     CK0(launch_nchw_to_nhwc<T>(dy, (long)Cout * H * W, Cout, nullptr, 0, ty, s));
     ConvArgs a; memset(&a, 0, sizeof a);
     a.in = yb; a.in_ld = cout_a; a.Cin = cout_a; a.wpk = wp; a.cin_pk = d.k_pk; a.cout_pk = d.rows_pk; a.taps = taps;
-    a.out = xin; a.out_ld = cin_a; a.Cout = cin_a; a.B = B; a.H = H; a.W = W; a.frag_layout = d.mode >= 2;
+    a.out = xin; a.out_ld = cin_a; a.Cout = cin_a; a.B = B; a.H = H; a.W = W; a.frag_layout = d.mode >= 2; a.mfma16 = m16;
     CK0(launch_conv<T>(a, s));
     CK0(launch_nhwc_to_nchw<T>(tx, Cin, out, 0, s));
   } else {
@@ -1434,12 +1444,14 @@ static int bench_conv_t(int mode, int ks, int B, int Cin, int Cout, int H, int W
   if (mode == 0 || mode == 1) {
     const int ci = mode == 0 ? Cin : Cout, co = mode == 0 ? Cout : Cin;
     d.Cout = co; d.Cin = ci; d.rows_pk = rup(co, 32); d.k_pk = rup(ci, 32); d.mode = conv_uses_frag_layout((int)esz, H, W) ? 2 : 0;
+    const bool m16 = d.mode == 2 && conv_uses_mfma16((int)esz, taps, d.k_pk, co, H, W);
+    if (m16) d.mode = 6;
     CK0(hipMalloc(&wp, (size_t)d.rows_pk * taps * d.k_pk * esz));
     CK0(hipMemcpyAsync(dd, &d, sizeof d, hipMemcpyHostToDevice, s));
     CK0(launch_pack<T>(wf, wp, dd, 1, s));
     ConvArgs a; memset(&a, 0, sizeof a);
     a.in = mode == 0 ? (void*)xin : (void*)yb; a.in_ld = ci; a.Cin = ci; a.wpk = wp; a.cin_pk = d.k_pk; a.cout_pk = d.rows_pk; a.taps = taps;
-    a.out = mode == 0 ? (void*)yb : (void*)xin; a.out_ld = co; a.Cout = co; a.B = B; a.H = H; a.W = W; a.frag_layout = d.mode >= 2;
+    a.out = mode == 0 ? (void*)yb : (void*)xin; a.out_ld = co; a.Cout = co; a.B = B; a.H = H; a.W = W; a.frag_layout = d.mode >= 2; a.mfma16 = m16;
     for (int i = 0; i < 3; ++i) CK0(launch_conv<T>(a, s));
     CK0(hipEventRecord(e0, s));
     for (int i = 0; i < iters; ++i) CK0(launch_conv<T>(a, s));

@@ -1,6 +1,7 @@
 // Kernel launch interface shared by the engine and the kernel translation units.
 #pragma once
 #include "pu_common.h"
+#include <cstdlib>
 
 namespace pu {
 
@@ -14,6 +15,7 @@ struct ConvArgs {
   int B, H, W;
   int relu; int accumulate;
   int frag_layout;                               // 1: wpk is fragment-major (conv3 kernel), see conv_uses_frag_layout()
+  int mfma16;                                    // 1: wpk holds v_mfma_f32_16x16x32 fragments (conv_uses_mfma16(); PackDesc mode bit 2)
   // Fused GroupNorm statistics of the OUTPUT (optional): each wave adds the (sum, sum of squares) of the values it stores
   // into its own row  stat_out[((b * slots + slot) * Cout + c) * 2 + {0,1}]  (written, never accumulated -> deterministic).
   // The launcher reports the slot count per image of the tiling it chose through *stat_slots (host pointer; 0 = this
@@ -26,6 +28,28 @@ inline bool conv_uses_frag_layout(int elem_size, int H, int W) {
   return elem_size == 2 && ((W % 32 == 0 && H % 8 == 0) || (W % 16 == 0 && H % 16 == 0));
 }
 // A split-K weight gradient whose slabs still have to be summed (fixed order) and added into the fp32 gradient.
+// Routing of a fragment-major convolution (shared by the launcher and by the weight packer, which must agree on the fragment shape):
+// true -> the persistent, weight-resident conv3p_kernel (K <= 64 input channels; 32x32x16 fragments), false -> conv3_kernel.
+inline bool conv3_goes_persistent(int cin_pk, int Cout, int H, int W) {
+  static const int c64_mode = getenv("PU_C64_MODE") ? atoi(getenv("PU_C64_MODE")) : 1;   // 64 -> 64 class: 1 = conv3 on 256-pixel tiles (default),
+                                                                                        // 0 = conv3 on 128-pixel tiles, 2 = conv3p
+  static const bool no_conv3p = getenv("PU_NO_CONV3P") != nullptr;                       // diagnostic switch
+  if (cin_pk > 64 || no_conv3p) return false;
+  if (cin_pk == 64 && Cout > 32 && Cout <= 64 && W % 32 == 0 && ((H % 8 == 0 && c64_mode == 1) || (H % 4 == 0 && c64_mode == 0))) return false;
+  if (!((W % 32 == 0 && H % 8 == 0) || (W % 16 == 0 && H % 16 == 0))) return false;
+  if (Cout > 64 && cin_pk == 64) return false;          // two chunks of weights + 80 KB of staging exceed the LDS
+  return true;
+}
+// conv3_kernel runs on v_mfma_f32_16x16x32 fragments (weights packed [cout tile][chunk][tap][cout half][lane][8], PackDesc mode bit 2):
+// same FLOPs per cycle as 32x32x16, but the chip holds a higher clock on that shape under load (+10...13 % on the MFMA-bound
+// convolutions, tools/conv_microbench.py A/B).  PU_MFMA16=0 switches back.
+inline bool conv_uses_mfma16(int elem_size, int taps, int cin_pk, int Cout, int H, int W) {
+  static const int mode = getenv("PU_MFMA16") ? atoi(getenv("PU_MFMA16")) : 1;
+  (void)taps;
+  // only the cout-split instances (WM = 1, WN = 4: more than 64 output channels): the <..,2,2> / <..,4,1> instances need 270 registers
+  // in this form and lose their second resident block (64 -> 64 @128x128: 608 -> 462 TFLOP/s)
+  return mode != 0 && Cout > 64 && conv_uses_frag_layout(elem_size, H, W) && !conv3_goes_persistent(cin_pk, Cout, H, W);
+}
 struct WgradReduce { const float* slab; int split, taps, cout_pad, cin_pad, Cout, Cin; float* dw; float inv_scale; float* db0; float* db1; const float* inv_dev; };
 struct WgradArgs {
   const void* dy; int dy_ld; int Cout;
