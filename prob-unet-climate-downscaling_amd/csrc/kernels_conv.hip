@@ -344,7 +344,7 @@ static inline void stat_resolve(ConvArgs& a, int slots) {
 // [pixel][32 ch] LDS rows of 96 bytes (conflict-free for the lane -> (pixel = l & 15, 8 channels at 8 (l >> 4)) fragment) and
 // weights packed as [cout tile][chunk][tap][cout half][lane][8] (PackDesc mode bit 2).
 template <typename T, int KS, int TH, int TW, int WM, int WN, int MS = 32>
-__global__ __launch_bounds__(64 * WM * WN) void conv3_kernel(ConvArgs a) {
+__global__ __launch_bounds__(64 * WM * WN, (MS == 16 && TH * TW / WM <= 128) ? 2 : 1) void conv3_kernel(ConvArgs a) {
   typedef MM<T> M;
   constexpr int NT = 64 * WM * WN;
   constexpr int BM = TH * TW;

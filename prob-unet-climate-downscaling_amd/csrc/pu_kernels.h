@@ -46,9 +46,11 @@ inline bool conv3_goes_persistent(int cin_pk, int Cout, int H, int W) {
 inline bool conv_uses_mfma16(int elem_size, int taps, int cin_pk, int Cout, int H, int W) {
   static const int mode = getenv("PU_MFMA16") ? atoi(getenv("PU_MFMA16")) : 1;
   (void)taps;
-  // only the cout-split instances (WM = 1, WN = 4: more than 64 output channels): the <..,2,2> / <..,4,1> instances need 270 registers
-  // in this form and lose their second resident block (64 -> 64 @128x128: 608 -> 462 TFLOP/s)
-  return mode != 0 && Cout > 64 && conv_uses_frag_layout(elem_size, H, W) && !conv3_goes_persistent(cin_pk, Cout, H, W);
+  // mode 2: only the cout-split instances (more than 64 output channels).  The <..,2,2> / <..,4,1> instances need
+  // __launch_bounds__(256, 2) in this form to keep their second resident block (270 -> 242 registers; without it 64 -> 64 @128x128 fell
+  // from 608 to 462 TFLOP/s)
+  if (mode == 2 && Cout <= 64) return false;
+  return mode != 0 && conv_uses_frag_layout(elem_size, H, W) && !conv3_goes_persistent(cin_pk, Cout, H, W);
 }
 struct WgradReduce { const float* slab; int split, taps, cout_pad, cin_pad, Cout, Cin; float* dw; float inv_scale; float* db0; float* db1; const float* inv_dev; };
 struct WgradArgs {
