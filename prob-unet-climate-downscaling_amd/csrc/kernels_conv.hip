@@ -102,6 +102,10 @@ template <> __device__ __forceinline__ void store4<bf16>(bf16* p, const float* o
 
 constexpr int KC = 32;     // channels staged per K chunk
 
+// 16 zero bytes in device memory: out-of-image / beyond-Cin staging vectors are LOADED from here instead of being loaded from a
+// dummy address and zeroed by a select - a select next to the load makes the wave wait for the load at once (see conv3_kernel)
+__device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
+
 // Diagnostic builds only (tools/ablate_conv.sh compiles extra copies of the library with -DPU_ABLATE=<bits>; results are wrong by
 // design, only the timing is read): 1 = weight fragments always from chunk 0 of tile 0 (L1/L2-hot), 2 = halo tile staged once,
 // 4 = no block barriers in the chunk loop, 8 = no LDS fragment reads, 16 = no output stores.  Production: 0.
@@ -408,25 +412,22 @@ __global__ __launch_bounds__(64 * WM * WN, (MS == 16 && TH * TW / WM <= 128) ? 2
     }
   }
   V16 ri[NVI];
-  // branch-free staging loads: out-of-image / beyond-Cin vectors read a valid dummy address and are zeroed by a select, so the
-  // whole chunk body stays one basic block.  The select is applied when the vector is WRITTEN to LDS (end of the chunk), not
-  // where it is loaded: a select next to the load made every chunk start with s_waitcnt vmcnt(0) - the halo loads AND the 18
-  // weight-fragment loads in flight drained before the first MFMA of the chunk (half of a wave's cycles).
-  auto gok = [&](int k, int c0) -> bool { return gi[k] >= 0 && c0 + (li[k] % KCP) < a.Cin; };
+  // branch-free staging loads: out-of-image / beyond-Cin vectors are loaded from a 16-byte zero page (g_zero16), so the whole chunk
+  // body stays one basic block and NOTHING post-processes a loaded vector.  (Round 1 loaded a dummy address and zeroed it with a
+  // select next to the load: every chunk then started with s_waitcnt vmcnt(0) - the halo loads AND the 18 weight-fragment loads in
+  // flight drained before the first MFMA of the chunk.)
+  const ptrdiff_t zoff = reinterpret_cast<const T*>(g_zero16) - in;
   auto gload = [&](int c0) {
 #pragma unroll
-    for (int k = 0; k < NVI; ++k)
-      ri[k] = *reinterpret_cast<const V16*>(in + (gok(k, c0) ? (size_t)(unsigned)gi[k] + c0 : (size_t)0));
+    for (int k = 0; k < NVI; ++k) {
+      const bool ok = gi[k] >= 0 && c0 + (li[k] % KCP) < a.Cin;
+      const V16 v = *reinterpret_cast<const V16*>(in + (ok ? (ptrdiff_t)((size_t)(unsigned)gi[k] + c0) : zoff));
+      ri[k].w[0] = v.w[0]; ri[k].w[1] = v.w[1]; ri[k].w[2] = v.w[2]; ri[k].w[3] = v.w[3];
+    }
   };
-  auto lstore = [&](int buf, int c0) {
+  auto lstore = [&](int buf, int) {
 #pragma unroll
-    for (int k = 0; k < NVI; ++k)
-      if (li[k] >= 0) {
-        const bool ok = gok(k, c0);
-        V16 v;
-        v.w[0] = ok ? ri[k].w[0] : 0u; v.w[1] = ok ? ri[k].w[1] : 0u; v.w[2] = ok ? ri[k].w[2] : 0u; v.w[3] = ok ? ri[k].w[3] : 0u;
-        *reinterpret_cast<V16*>(sIn + buf * BUF + li[k]) = v;
-      }
+    for (int k = 0; k < NVI; ++k) if (li[k] >= 0) *reinterpret_cast<V16*>(sIn + buf * BUF + li[k]) = ri[k];
   };
   typename M::Frag fa[TAPS][2];
   const T* wbase = have_w ? wfrag : reinterpret_cast<const T*>(a.wpk) + l * 8;     // idle waves read tile 0 (never stored)
@@ -694,6 +695,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3p_kernel(ConvArgs a) {
   }
 
   V16 ri[NCH][NVI];
+  const ptrdiff_t zoff = reinterpret_cast<const T*>(g_zero16) - in;
   auto gload = [&](int tile) {
     int pt = tile;
     const int tx0 = (pt % tiles_x) * TW; pt /= tiles_x;
@@ -711,8 +713,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3p_kernel(ConvArgs a) {
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
         const bool ok = inimg && c * KC + cv * 8 < a.Cin;
-        const V16 v = *reinterpret_cast<const V16*>(in + (ok ? off + c * KC : (size_t)0));
-        ri[c][k].w[0] = ok ? v.w[0] : 0u; ri[c][k].w[1] = ok ? v.w[1] : 0u; ri[c][k].w[2] = ok ? v.w[2] : 0u; ri[c][k].w[3] = ok ? v.w[3] : 0u;
+        // (element offset of the zero page relative to `in`: one offset select per vector, as branch-free as the dummy-address form)
+        const V16 v = *reinterpret_cast<const V16*>(in + (ok ? (ptrdiff_t)(off + c * KC) : zoff));   // no post-processing: stays in flight
+        ri[c][k].w[0] = v.w[0]; ri[c][k].w[1] = v.w[1]; ri[c][k].w[2] = v.w[2]; ri[c][k].w[3] = v.w[3];
       }
     }
   };
