@@ -21,6 +21,10 @@ int pu_op_conv(int dtype, int mode, int ks, int relu, int B, int Cin, int Cout, 
 /* Micro-benchmark: average microseconds (HIP events, `iters` back-to-back launches) of one convolution kernel launch on
  * NHWC data already in HBM. mode 0 forward, 1 data gradient, 2 weight gradient (incl. its slab reduce). Syncs. */
 int pu_bench_conv(int dtype, int mode, int ks, int B, int Cin, int Cout, int H, int W, int iters, float* out_us, void* stream);
+/* Micro-benchmark of the GroupNorm+SiLU kernels on random NHWC 16-bit data [B,H,W,C] (C % 8 == 0): out_us[0] apply, [1] backward pass 1,
+ * [2] backward pass 2, [3] the single-kernel backward of small tensors (0 where it does not apply), each the average of `iters`
+ * back-to-back launches.  flags: 1 = pass 2 accumulates into dx, 2 = pass 2 adds an extra tensor. */
+int pu_bench_gn(int dtype, int resample, int B, int C, int H, int W, float drop_p, int flags, int iters, float* out_us, void* stream);
 /* GroupNorm(+scale/shift)+SiLU(+dropout drop_p with the counter-hash mask of drop_seed; resample 0 only) with optional
  * 2x resample (0 none, 1 avg-pool down, 2 nearest up), forward and backward, on NCHW fp32 tensors. Syncs. */
 int pu_op_gnsilu(int dtype, int resample, int B, int C, int H, int W, const float* x, const float* gamma,

@@ -105,6 +105,8 @@ def lib():
     L.pu_op_conv.argtypes = [i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp]
     L.pu_bench_conv.restype = i32
     L.pu_bench_conv.argtypes = [i32, i32, i32, i32, i32, i32, i32, i32, i32, C.POINTER(C.c_float), vp]
+    L.pu_bench_gn.restype = i32
+    L.pu_bench_gn.argtypes = [i32, i32, i32, i32, i32, i32, C.c_float, i32, i32, C.POINTER(C.c_float), vp]
     L.pu_op_gnsilu.restype = i32
     L.pu_op_gnsilu.argtypes = [i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, u64, vp]
     _lib = L

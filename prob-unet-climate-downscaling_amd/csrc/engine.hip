@@ -1480,6 +1480,72 @@ extern "C" int pu_bench_conv(int dtype, int mode, int ks, int B, int Cin, int Co
   return PU_ERR_INVALID;
 }
 
+// micro-benchmark of the GroupNorm kernels on random NHWC data: out_us[0] apply, [1] backward pass 1, [2] backward pass 2,
+// [3] single-kernel small-tensor backward (0 where it does not apply); flags: 1 = accumulate into dx, 2 = extra addend
+template <typename T>
+static int bench_gn_t(int resample, int B, int C, int H, int W, float drop_p, int flags, int iters, float* out_us, hipStream_t s) {
+  int rc = PU_OK;
+  const size_t esz = sizeof(T);
+  const int OH = resample == RS_DOWN ? H / 2 : (resample == RS_UP ? H * 2 : H), OW = resample == RS_DOWN ? W / 2 : (resample == RS_UP ? W * 2 : W);
+  const long nin = (long)B * H * W * C, nout = (long)B * OH * OW * C;
+  T *xb = nullptr, *yb = nullptr, *dyb = nullptr, *dxb = nullptr, *adb = nullptr; float *ws = nullptr, *par = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr; float ms = 0.f;
+  const int G = gn_groups(C), nchunk = gn_chunks((long)H * W);
+  const size_t nws = (size_t)B * nchunk * C * 2 * 2 + (size_t)B * G * 2 + 4 + (size_t)B * C * 4 + (size_t)B * C * 3;
+  GNArgs a; GNBwdArgs bw; TV tx, ty;
+  CK0(hipMalloc(&xb, nin * esz)); CK0(hipMalloc(&yb, nout * esz)); CK0(hipMalloc(&dyb, nout * esz)); CK0(hipMalloc(&dxb, nin * esz));
+  CK0(hipMalloc(&adb, nin * esz)); CK0(hipMalloc(&ws, nws * sizeof(float))); CK0(hipMalloc(&par, (size_t)C * 8 * sizeof(float)));
+  hipLaunchKernelGGL(rand_fill_kernel<T>, dim3(4096), dim3(256), 0, s, xb, nin, 5u);
+  hipLaunchKernelGGL(rand_fill_kernel<T>, dim3(4096), dim3(256), 0, s, dyb, nout, 6u);
+  hipLaunchKernelGGL(rand_fill_kernel<T>, dim3(4096), dim3(256), 0, s, adb, nin, 7u);
+  hipLaunchKernelGGL(rand_fill_kernel<T>, dim3(4096), dim3(256), 0, s, dxb, nin, 8u);
+  hipLaunchKernelGGL(rand_fill_kernel<float>, dim3(8), dim3(256), 0, s, par, (long)C * 8, 9u);
+  CK0(hipGetLastError());
+  CK0(hipEventCreate(&e0)); CK0(hipEventCreate(&e1));
+  tx.p = xb; tx.B = B; tx.H = H; tx.W = W; tx.C = C; tx.ld = C;
+  ty.p = yb; ty.B = B; ty.H = OH; ty.W = OW; ty.C = C; ty.ld = C;
+  memset(&a, 0, sizeof a);
+  a.x = tx; a.y = ty; a.G = G; a.eps = 1e-5f; a.gamma = par; a.beta = par + C; a.resample = resample;
+  a.drop_p = resample == RS_NONE ? drop_p : 0.f; a.drop_seed = 1234; a.drop_stream = 7;
+  a.part = ws; a.nchunk = nchunk; a.stat = ws + (size_t)B * nchunk * C * 2; a.coef = a.stat + (((size_t)B * G * 2 + 3) & ~(size_t)3);
+  CK0(launch_gn_fwd<T>(a, s));
+  {
+    TV tdy = ty; tdy.p = dyb; TV tdx = tx; tdx.p = dxb; TV tad = tx; tad.p = adb;
+    memset(&bw, 0, sizeof bw);
+    bw.f = a; bw.dy = tdy; bw.dx = tdx; bw.accumulate = flags & 1; if (flags & 2) bw.add = tad;
+    bw.dgamma = par + 2 * C; bw.dbeta = par + 3 * C;
+    bw.part2 = a.coef + (size_t)B * C * 4; bw.coef2 = bw.part2 + (size_t)B * nchunk * C * 2; bw.inv_scale = 1.f;
+  }
+  CK0(launch_gn_bwd_parts<T>(bw, 7, s));
+  for (int k = 0; k < 4; ++k) {
+    out_us[k] = 0.f;
+    int cb = 0;
+    if (k == 3 && !(sizeof(T) == 2 && resample == RS_NONE && (long)H * W <= 1024 && C % 8 == 0)) continue;
+    auto run = [&]() -> hipError_t {
+      if (k == 0) return launch_gn_apply<T>(a, s);
+      return launch_gn_bwd_parts<T>(bw, k == 1 ? 1 : (k == 2 ? 2 : 8), s);
+    };
+    (void)cb;
+    if (run() != hipSuccess) { (void)hipGetLastError(); continue; }
+    CK0(hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i) CK0(run());
+    CK0(hipEventRecord(e1, s));
+    CK0(hipEventSynchronize(e1)); CK0(hipEventElapsedTime(&ms, e0, e1));
+    out_us[k] = 1e3f * ms / iters;
+  }
+done:
+  (void)hipFree(xb); (void)hipFree(yb); (void)hipFree(dyb); (void)hipFree(dxb); (void)hipFree(adb); (void)hipFree(ws); (void)hipFree(par);
+  if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1);
+  return rc;
+}
+extern "C" int pu_bench_gn(int dtype, int resample, int B, int C, int H, int W, float drop_p, int flags, int iters, float* out_us, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (C % 8 || iters < 1) return PU_ERR_INVALID;
+  if (dtype == PU_F16) return bench_gn_t<f16>(resample, B, C, H, W, drop_p, flags, iters, out_us, s);
+  if (dtype == PU_BF16) return bench_gn_t<bf16>(resample, B, C, H, W, drop_p, flags, iters, out_us, s);
+  return PU_ERR_INVALID;
+}
+
 extern "C" int pu_op_gnsilu(int dtype, int resample, int B, int C, int H, int W, const float* x, const float* gamma, const float* beta,
                  const float* ss, float* y, const float* dy, float* dx, float* dgamma, float* dbeta, float* dss,
                  float drop_p, uint64_t drop_seed, void* stream) {

@@ -2,6 +2,7 @@
 // (+adaptive scale/shift, dropout, 2x resample) forward/backward, max-pool, ReLU backward, bias gradient,
 // Gaussian-encoder heads, latent sampling + KL, afCRPS / L1 reconstruction loss.
 // Every kernel moves 16 bytes per lane along the channel axis (contiguous in NHWC).
+#include <cstdio>
 #include <cstdlib>
 
 #include "pu_kernels.h"
@@ -344,9 +345,32 @@ static inline GNArgs gn_sub(const GNArgs& a, int b0, int nb, size_t esz) {
   return q;
 }
 
+// per-shape event timing of the GroupNorm kernels (tools/gn_profile.py): PU_PROF_GN=1 together with pu_profile_enable(1)
+static inline bool gn_prof() {
+  static const bool on = getenv("PU_PROF_GN") != nullptr;
+  return on && prof_enabled();
+}
+static inline void gn_prof_begin(const char* what, int rs, const TV& x, double bytes, hipStream_t s, int ld1 = 0, int ld2 = 0, int fl = 0) {
+  char tag[128];
+  snprintf(tag, sizeof tag, "%s<rs%d>[%dx%dx%dx%d] ld %d,%d,%d f%d", what, rs, x.B, x.H, x.W, x.C, x.ld, ld1, ld2, fl);
+  prof_record(tag, 0, bytes, s, true);
+}
+
+// the apply kernel alone (statistics / coefficients already in place); also the unit timed by pu_bench_gn
+template <typename T>
+hipError_t launch_gn_apply(const GNArgs& a, hipStream_t s) {
+  const dim3 ga(gn_pix_blocks((long)a.y.H * a.y.W, a.x.C / ET<T>::VEC, a.x.B), a.x.B);
+  const bool prof = gn_prof();
+  if (prof) gn_prof_begin("gn_apply", a.resample, a.x, ((double)a.x.B * a.x.H * a.x.W + (double)a.y.B * a.y.H * a.y.W) * a.x.C * sizeof(T), s, a.y.ld, 0, a.drop_p > 0.f);
+  if (a.resample == RS_NONE) hipLaunchKernelGGL((gn_apply_kernel<T, RS_NONE>), ga, dim3(256), 0, s, a);
+  else if (a.resample == RS_DOWN) hipLaunchKernelGGL((gn_apply_kernel<T, RS_DOWN>), ga, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((gn_apply_kernel<T, RS_UP>), ga, dim3(256), 0, s, a);
+  if (prof) prof_record("", 0, 0, s, false);
+  return hipGetLastError();
+}
+
 template <typename T>
 hipError_t launch_gn_fwd(const GNArgs& a0, hipStream_t s) {
-  const long HW = (long)a0.x.H * a0.x.W;
   const int step = gn_batch_chunk(a0.x, sizeof(T));
   for (int b0 = 0; b0 < a0.x.B; b0 += step) {
     const int nb = min(step, a0.x.B - b0);
@@ -355,11 +379,8 @@ hipError_t launch_gn_fwd(const GNArgs& a0, hipStream_t s) {
     if (!fused) hipLaunchKernelGGL((chan_partial_kernel<T, true>), dim3(a.nchunk, a.x.B), dim3(256), 0, s, a.x, a.part, a.nchunk, 1);
     hipLaunchKernelGGL((gn_finalize_kernel<T, 1024>), dim3(a.x.B), dim3(1024), 0, s, a.x, a.part, a.nchunk, a.G, a.eps, a.gamma, a.beta,
                        a.scale, a.shift, a.stat, a.coef, fused ? a.ps0 : nullptr, a.ns0, a.pc0, a.ps1, a.ns1);
-    (void)HW;
-    const dim3 ga(gn_pix_blocks((long)a.y.H * a.y.W, a.x.C / ET<T>::VEC, a.x.B), a.x.B);
-    if (a.resample == RS_NONE) hipLaunchKernelGGL((gn_apply_kernel<T, RS_NONE>), ga, dim3(256), 0, s, a);
-    else if (a.resample == RS_DOWN) hipLaunchKernelGGL((gn_apply_kernel<T, RS_DOWN>), ga, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((gn_apply_kernel<T, RS_UP>), ga, dim3(256), 0, s, a);
+    hipError_t e = launch_gn_apply<T>(a, s);
+    if (e != hipSuccess) return e;
   }
   return hipGetLastError();
 }
@@ -748,6 +769,55 @@ __global__ __launch_bounds__(256) void gn_small_bwd_kernel(GNBwdArgs a, int CB) 
   }
 }
 
+// One part of the backward: 1 = pass 1, 2 = pass 2, 4 = the coefficient kernel between them, 8 = the single-kernel small-tensor form
+// (launch_gn_bwd picks 8 or 1|4|2; pu_bench_gn times the parts one at a time).
+template <typename T>
+static inline bool gn_bwd_is_small(const GNArgs& f, int* cb_out) {
+  if constexpr (sizeof(T) == 2) {
+    static const bool no_small = getenv("PU_NO_GN_SMALL") != nullptr;
+    const int cb = gn_bundle_channels(f.x.C, f.G);
+    *cb_out = cb;
+    return !no_small && f.resample == RS_NONE && (long)f.x.H * f.x.W <= 1024 && cb > 0;
+  }
+  *cb_out = 0;
+  return false;
+}
+template <typename T>
+hipError_t launch_gn_bwd_parts(const GNBwdArgs& a, int parts, hipStream_t s) {
+  const GNArgs& f = a.f;
+  const bool prof = gn_prof();
+  const double xb = (double)f.x.B * f.x.H * f.x.W * f.x.C * sizeof(T), dyb = (double)a.dy.B * a.dy.H * a.dy.W * f.x.C * sizeof(T);
+  const double p2b = xb + dyb + xb * (1 + (a.accumulate ? 1 : 0) + (a.add.p ? 1 : 0));
+  if (parts & 8) {
+    int cb = 0;
+    if (!gn_bwd_is_small<T>(f, &cb)) return hipErrorInvalidValue;
+    if constexpr (sizeof(T) == 2) {
+      if (prof) gn_prof_begin("gn_small_bwd", f.resample, f.x, p2b, s, a.dy.ld, a.dx.ld, (f.drop_p > 0.f) + 2 * a.accumulate + 4 * (a.add.p != nullptr));
+      hipLaunchKernelGGL(gn_small_bwd_kernel<T>, dim3(f.x.C / cb, f.x.B), dim3(256), 0, s, a, cb);
+      if (prof) prof_record("", 0, 0, s, false);
+    }
+    return hipGetLastError();
+  }
+  if (parts & 1) {
+    dim3 g1(f.nchunk, f.x.B);
+    if (prof) gn_prof_begin("gn_bwd_pass1", f.resample, f.x, xb + dyb, s, a.dy.ld, a.dx.ld, (f.drop_p > 0.f) + 2 * a.accumulate + 4 * (a.add.p != nullptr));
+    if (f.resample == RS_NONE) hipLaunchKernelGGL((gn_bwd_pass1_kernel<T, RS_NONE>), g1, dim3(256), 0, s, a);
+    else if (f.resample == RS_DOWN) hipLaunchKernelGGL((gn_bwd_pass1_kernel<T, RS_DOWN>), g1, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((gn_bwd_pass1_kernel<T, RS_UP>), g1, dim3(256), 0, s, a);
+    if (prof) prof_record("", 0, 0, s, false);
+  }
+  if (parts & 4) hipLaunchKernelGGL(gn_bwd_finalize_kernel<1024>, dim3(f.x.B), dim3(1024), 0, s, a);
+  if (parts & 2) {
+    const dim3 g2(gn_pix_blocks((long)f.x.H * f.x.W, f.x.C / ET<T>::VEC, f.x.B), f.x.B);
+    if (prof) gn_prof_begin("gn_bwd_pass2", f.resample, f.x, p2b, s, a.dy.ld, a.dx.ld, (f.drop_p > 0.f) + 2 * a.accumulate + 4 * (a.add.p != nullptr));
+    if (f.resample == RS_NONE) hipLaunchKernelGGL((gn_bwd_pass2_kernel<T, RS_NONE>), g2, dim3(256), 0, s, a);
+    else if (f.resample == RS_DOWN) hipLaunchKernelGGL((gn_bwd_pass2_kernel<T, RS_DOWN>), g2, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((gn_bwd_pass2_kernel<T, RS_UP>), g2, dim3(256), 0, s, a);
+    if (prof) prof_record("", 0, 0, s, false);
+  }
+  return hipGetLastError();
+}
+
 template <typename T>
 hipError_t launch_gn_bwd(const GNBwdArgs& a0, hipStream_t s) {
   const int step = gn_batch_chunk(a0.f.x, sizeof(T));
@@ -758,24 +828,9 @@ hipError_t launch_gn_bwd(const GNBwdArgs& a0, hipStream_t s) {
     a.dy = tv_batch(a0.dy, b0, nb, sizeof(T)); a.dx = tv_batch(a0.dx, b0, nb, sizeof(T)); a.dv = tv_batch(a0.dv, b0, nb, sizeof(T));
     a.add = tv_batch(a0.add, b0, nb, sizeof(T));
     a.part2 = a0.part2 + (size_t)b0 * a0.f.nchunk * a0.f.x.C * 2; a.coef2 = a0.coef2 + (size_t)b0 * a0.f.x.C * 3;
-    const GNArgs& f = a.f;
-    if constexpr (sizeof(T) == 2) {
-      static const bool no_small = getenv("PU_NO_GN_SMALL") != nullptr;
-      const int cb = gn_bundle_channels(f.x.C, f.G);
-      if (!no_small && f.resample == RS_NONE && (long)f.x.H * f.x.W <= 1024 && cb > 0) {
-        hipLaunchKernelGGL(gn_small_bwd_kernel<T>, dim3(f.x.C / cb, f.x.B), dim3(256), 0, s, a, cb);
-        continue;
-      }
-    }
-    dim3 g1(f.nchunk, f.x.B);
-    if (f.resample == RS_NONE) hipLaunchKernelGGL((gn_bwd_pass1_kernel<T, RS_NONE>), g1, dim3(256), 0, s, a);
-    else if (f.resample == RS_DOWN) hipLaunchKernelGGL((gn_bwd_pass1_kernel<T, RS_DOWN>), g1, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((gn_bwd_pass1_kernel<T, RS_UP>), g1, dim3(256), 0, s, a);
-    hipLaunchKernelGGL(gn_bwd_finalize_kernel<1024>, dim3(f.x.B), dim3(1024), 0, s, a);
-    const dim3 g2(gn_pix_blocks((long)f.x.H * f.x.W, f.x.C / ET<T>::VEC, f.x.B), f.x.B);
-    if (f.resample == RS_NONE) hipLaunchKernelGGL((gn_bwd_pass2_kernel<T, RS_NONE>), g2, dim3(256), 0, s, a);
-    else if (f.resample == RS_DOWN) hipLaunchKernelGGL((gn_bwd_pass2_kernel<T, RS_DOWN>), g2, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((gn_bwd_pass2_kernel<T, RS_UP>), g2, dim3(256), 0, s, a);
+    int cb = 0;
+    hipError_t e = launch_gn_bwd_parts<T>(a, gn_bwd_is_small<T>(a.f, &cb) ? 8 : 7, s);
+    if (e != hipSuccess) return e;
   }
   return hipGetLastError();
 }
@@ -1356,6 +1411,8 @@ hipError_t launch_nonfinite_flag(const float* g, long n, float* flag, hipStream_
   template hipError_t launch_nhwc_to_nchw<T>(TV, int, float*, int, hipStream_t);                                     \
   template hipError_t launch_gn_fwd<T>(const GNArgs&, hipStream_t);                                                  \
   template hipError_t launch_gn_bwd<T>(const GNBwdArgs&, hipStream_t);                                               \
+  template hipError_t launch_gn_apply<T>(const GNArgs&, hipStream_t);                                                \
+  template hipError_t launch_gn_bwd_parts<T>(const GNBwdArgs&, int, hipStream_t);                                    \
   template hipError_t launch_resample<T>(TV, TV, int, hipStream_t);                                                  \
   template hipError_t launch_resample_bwd<T>(TV, TV, int, int, hipStream_t);                                         \
   template hipError_t launch_add<T>(TV, TV, int, hipStream_t);                                                       \

@@ -313,11 +313,175 @@ static hipError_t launch_wg16(const WgradArgs& a, hipStream_t s, WgradReduce* re
   red->dw = a.dw; red->inv_scale = a.inv_scale; red->db0 = a.dbias0; red->db1 = a.dbias1; red->inv_dev = a.inv_scale_dev;
   return hipGetLastError();
 }
+
+// Second form of the slab reduction (default; PU_WG_REDUCE_OLD=1 selects the kernel above).  What the profile of the first form showed:
+//  * layers with small tiles and deep splits (32 x 32 x 9 tile, 512 slabs) ran 37 blocks whose threads each walked 128 dependent
+//    loads (31.7 us for 18.9 MB);
+//  * layers with large weight tensors (512 x 512 x 9 and up) spent their time in the 4-byte read-modify-write of dw at stride `taps`:
+//    one 64-byte line of dw[co][ci][tap] was touched by nine different blocks (80 us for a 75 MB slab set).
+// Here a block is UB = 256 / L units x L split lanes (L = 4 or 16, picked per launch so that the grid fills the chip), and with
+// ALLT a unit is one (cout, 4 x cin) position whose thread walks ALL taps: its nine float4 sums are the 36 consecutive floats
+// dw[co][ci .. ci+3][0 .. 8], written as nine 16-byte read-modify-writes.  Sums stay in a fixed order (lane-serial over the slabs,
+// then a fixed pairwise tree over the lanes), so results are reproducible run to run.
+template <int TAPS, int L, bool ALLT>
+__global__ __launch_bounds__(256) void wgrad_reduce2_kernel(const float* __restrict__ slab, int split, int cout_pad, int cin_pad, int Cout, int Cin,
+                                                             float* __restrict__ dw, float inv_scale, float* db0, float* db1,
+                                                             const float* __restrict__ inv_dev, unsigned nwb, int vec_ok) {
+  constexpr int UB = 256 / L, NT = ALLT ? TAPS : 1;
+  __shared__ f32x4 red[NT][256];
+  if (inv_dev) inv_scale *= inv_dev[0];            // device-chosen scale of this sub-graph (latent encoders, f16)
+  const long per_tap = (long)cout_pad * cin_pad;
+  const size_t stride = (size_t)TAPS * per_tap;
+  if (blockIdx.x >= nwb) {
+    // bias rows (slab tail [split][cout_pad]): 16 couts x 16 split lanes per block, eight loads in flight per thread.  (One block of
+    // 64 couts x 4 lanes walking split / 4 dependent-latency loads was what a 512-slab launch actually waited for: 32 us.)
+    float* bred = reinterpret_cast<float*>(&red[0][0]);
+    const int co = (int)(blockIdx.x - nwb) * 16 + (threadIdx.x & 15);
+    const int bl = threadIdx.x >> 4;
+    const float* bs = slab + (size_t)split * stride + (co < cout_pad ? co : 0);
+    float sb[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sb[i] = 0.f;
+    int k = bl;
+    for (; k + 7 * 16 < split; k += 8 * 16) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) sb[i] += bs[(size_t)(k + i * 16) * cout_pad];
+    }
+    for (; k < split; k += 16) sb[0] += bs[(size_t)k * cout_pad];
+    bred[threadIdx.x] = ((sb[0] + sb[1]) + (sb[2] + sb[3])) + ((sb[4] + sb[5]) + (sb[6] + sb[7]));
+    __syncthreads();
+    if (bl == 0 && co < Cout) {
+      float v = 0.f;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v += bred[j * 16 + threadIdx.x];
+      v *= inv_scale;
+      db0[co] += v;
+      if (db1) db1[co] += v;
+    }
+    return;
+  }
+  const int u = threadIdx.x % UB, lane = threadIdx.x / UB;
+  const long unit = (long)blockIdx.x * UB + u;
+  const long nunits = (ALLT ? per_tap : (long)TAPS * per_tap) / 4;
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  int ci = 0, co = 0, t0 = 0;
+  bool live = false;
+  if (unit < nunits) {
+    const long e = unit * 4;
+    ci = (int)(e % cin_pad);
+    const long q = e / cin_pad;
+    co = (int)(q % cout_pad); t0 = (int)(q / cout_pad);      // t0 == 0 with ALLT
+    live = co < Cout && ci < Cin;
+    if (live) {
+      const float* p = slab + e;
+      if (ALLT && NT > 1) {
+        for (int k = lane; k < split; k += L) {              // NT independent 16-byte loads in flight per trip
+          const float* pk = p + (size_t)k * stride;
+          f32x4 v[NT];
+#pragma unroll
+          for (int t = 0; t < NT; ++t) v[t] = *reinterpret_cast<const f32x4*>(pk + (size_t)t * per_tap);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[t] += v[t];
+        }
+      } else {
+        f32x4 sa[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) sa[i] = acc[0];
+        int k = lane;
+        for (; k + 7 * L < split; k += 8 * L) {              // eight independent 16-byte loads in flight per trip
+          f32x4 v[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const f32x4*>(p + (size_t)(k + i * L) * stride);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) sa[i] += v[i];
+        }
+        for (; k < split; k += L) sa[0] += *reinterpret_cast<const f32x4*>(p + (size_t)k * stride);
+        acc[0] = ((sa[0] + sa[1]) + (sa[2] + sa[3])) + ((sa[4] + sa[5]) + (sa[6] + sa[7]));
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) red[t][threadIdx.x] = acc[t];
+  // pairwise tree over the split lanes (lane j += lane j + h for h = L/2 .. 1): every thread of the upper levels takes part, where a
+  // serial walk by the L == 64 blocks' four lane-0 threads (576 dependent LDS reads) cost more than the slab reads themselves
+#pragma unroll
+  for (int h = L / 2; h >= 1; h >>= 1) {
+    __syncthreads();
+    if (lane < h) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t) { acc[t] += red[t][threadIdx.x + h * UB]; if (h > 1) red[t][threadIdx.x] = acc[t]; }
+    }
+  }
+  if (lane != 0 || !live) return;
+  f32x4 v[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) v[t] = acc[t] * inv_scale;
+  if (ALLT) {
+    float* d = dw + ((size_t)co * Cin + ci) * TAPS;
+    if (vec_ok) {                                  // Cin % 4 == 0 and dw 16-byte aligned: TAPS float4 read-modify-writes of 4 * TAPS consecutive floats
+#pragma unroll
+      for (int m = 0; m < TAPS; ++m) {
+        f32x4 o = *reinterpret_cast<f32x4*>(d + 4 * m);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int f = 4 * m + j; o[j] += v[f % TAPS][f / TAPS]; }
+        *reinterpret_cast<f32x4*>(d + 4 * m) = o;
+      }
+    } else {
+#pragma unroll
+      for (int e4 = 0; e4 < 4; ++e4)
+        if (ci + e4 < Cin) {
+#pragma unroll
+          for (int t = 0; t < TAPS; ++t) d[(size_t)e4 * TAPS + t] += v[t][e4];
+        }
+    }
+  } else {
+    float* d = dw + ((size_t)co * Cin + ci) * TAPS + t0;
+#pragma unroll
+    for (int e4 = 0; e4 < 4; ++e4)
+      if (ci + e4 < Cin) d[(size_t)e4 * TAPS] += v[0][e4];
+  }
+}
+
+template <int TAPS, int L, bool ALLT>
+static void launch_reduce2(const WgradReduce& r, hipStream_t s) {
+  const long per_tap = (long)r.cout_pad * r.cin_pad;
+  const long nunits = (ALLT ? per_tap : (long)TAPS * per_tap) / 4;
+  constexpr int UB = 256 / L;
+  const unsigned nwb = (unsigned)((nunits + UB - 1) / UB);
+  const unsigned nbias_blocks = r.db0 ? (unsigned)cdiv(r.Cout, 16) : 0u;
+  const int vec_ok = (r.Cin % 4 == 0) && ((reinterpret_cast<uintptr_t>(r.dw) & 15) == 0);
+  hipLaunchKernelGGL((wgrad_reduce2_kernel<TAPS, L, ALLT>), dim3(nwb + nbias_blocks), dim3(256), 0, s, r.slab, r.split, r.cout_pad, r.cin_pad,
+                     r.Cout, r.Cin, r.dw, r.inv_scale, r.db0, r.db1, r.inv_dev, nwb, vec_ok);
+}
+template <int TAPS, bool ALLT>
+static void launch_reduce2_l(const WgradReduce& r, int L, hipStream_t s) {
+  if (L == 4) launch_reduce2<TAPS, 4, ALLT>(r, s);
+  else launch_reduce2<TAPS, 16, ALLT>(r, s);
+}
+
 hipError_t launch_wgrad16_reduce(const WgradReduce& r, hipStream_t s) {
-  const long total4 = (long)r.taps * r.cout_pad * r.cin_pad / 4;
-  const unsigned nbias_blocks = r.db0 ? (unsigned)cdiv(r.Cout, 64) : 0u;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total4 + 63) / 64) + nbias_blocks), dim3(256), 0, s, r.slab, r.split, r.taps,
-                     r.cout_pad, r.cin_pad, r.Cout, r.Cin, r.dw, r.inv_scale, r.db0, r.db1, r.inv_dev);
+  static const bool old_form = getenv("PU_WG_REDUCE_OLD") != nullptr;
+  if (old_form || (r.taps != 9 && r.taps != 1)) {
+    const long total4 = (long)r.taps * r.cout_pad * r.cin_pad / 4;
+    const unsigned nbias_blocks = r.db0 ? (unsigned)cdiv(r.Cout, 64) : 0u;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total4 + 63) / 64) + nbias_blocks), dim3(256), 0, s, r.slab, r.split, r.taps,
+                       r.cout_pad, r.cin_pad, r.Cout, r.Cin, r.dw, r.inv_scale, r.db0, r.db1, r.inv_dev);
+    return hipGetLastError();
+  }
+  // Split lanes per unit: 4 or 16 (a lane row of a block then reads >= 256 contiguous bytes of one slab; 64 lanes x 64-byte rows measured
+  // 36 us where this form takes ~10), 16 only when the split is that deep and 4 lanes would leave fewer than 1024 blocks.  All taps per
+  // thread only where that still gives >= 1024 blocks (weights of 256 x 256 x 9 and up - the layers whose dw does not stay in L2).
+  const long units_all = (long)r.cout_pad * r.cin_pad / 4;
+  const int lmax = r.split >= 16 ? 16 : 4;
+  auto nblocks = [](long units, int L) { return (units + 256 / L - 1) / (256 / L); };
+  const bool allt = r.taps == 1 || nblocks(units_all, lmax) >= 1024;
+  const long units = allt ? units_all : units_all * r.taps;
+  const int L = (nblocks(units, 4) < 1024 && lmax == 16) ? 16 : 4;
+  if (r.taps == 1) launch_reduce2_l<1, true>(r, L, s);
+  else if (allt) launch_reduce2_l<9, true>(r, L, s);
+  else launch_reduce2_l<9, false>(r, L, s);
   return hipGetLastError();
 }
 

@@ -114,6 +114,8 @@ struct GNBwdArgs {
   float* coef2;               // [B][C][3] (P, Q, R)
 };
 template <typename T> hipError_t launch_gn_bwd(const GNBwdArgs&, hipStream_t);
+template <typename T> hipError_t launch_gn_apply(const GNArgs&, hipStream_t);                  // apply kernel alone (coefficients in place)
+template <typename T> hipError_t launch_gn_bwd_parts(const GNBwdArgs&, int parts, hipStream_t); // 1 pass 1 | 4 coefficients | 2 pass 2, or 8 small
 
 template <typename T> hipError_t launch_resample(TV x, TV y, int mode, hipStream_t);                      // y = down/up(x)
 template <typename T> hipError_t launch_resample_bwd(TV dy, TV dx, int mode, int accumulate, hipStream_t); // adjoint
