@@ -280,32 +280,36 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNArgs a) {
     }
     return;
   }
-  for (long p = p0 + pl; p < p1; p += PL) {
-    const int oy = (int)(p / OW), ox = (int)(p - (long)oy * OW);
-    float o[VEC];
-    if (RS == RS_DOWN) {
+  // resampled forms: two (down: 4 source pixels each) or four (up: one source pixel each) output pixels per trip, loads first
+  constexpr int U = RS == RS_DOWN ? 2 : 4, NS = RS == RS_DOWN ? 4 : 1;
+  for (long p = p0 + pl; p < p1; p += (long)PL * U) {
+    V16 rx[U][NS];
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) o[e] = 0.f;
+    for (int u = 0; u < U; ++u) {
+      const long pp = p + (long)u * PL, q = pp < p1 ? pp : p;
+      const int oy = (int)(q / OW), ox = (int)(q - (long)oy * OW);
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int iy = 2 * oy + (q >> 1), ix = 2 * ox + (q & 1);
-        float v[VEC]; unpack<T>(ldv<T>(xp + (((long)b * a.x.H + iy) * a.x.W + ix) * a.x.ld + cv * VEC), v);
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) o[e] += 0.25f * silu_f<sizeof(T) == 4>(A[e] * (v[e] - mu[e]) + Bc[e]);
-      }
-    } else {
-      const int iy = RS == RS_UP ? oy >> 1 : oy, ix = RS == RS_UP ? ox >> 1 : ox;
-      float v[VEC]; unpack<T>(ldv<T>(xp + (((long)b * a.x.H + iy) * a.x.W + ix) * a.x.ld + cv * VEC), v);
-#pragma unroll
-      for (int e = 0; e < VEC; ++e) o[e] = silu_f<sizeof(T) == 4>(A[e] * (v[e] - mu[e]) + Bc[e]);
-      if (RS == RS_NONE && a.drop_p > 0.f) {
-        const uint64_t base = ((uint64_t)(b + a.b0) * OHW + p) * (uint64_t)C + (uint64_t)cv * VEC;
-        const uint32_t kb = drop_keep_bits<VEC>(a, dkey, dthr, base);
-#pragma unroll
-        for (int e = 0; e < VEC; ++e) o[e] = ((kb >> e) & 1u) ? o[e] * inv_keep : 0.f;
+      for (int k = 0; k < NS; ++k) {
+        const int iy = RS == RS_DOWN ? 2 * oy + (k >> 1) : oy >> 1, ix = RS == RS_DOWN ? 2 * ox + (k & 1) : ox >> 1;
+        rx[u][k] = ldv<T>(xp + (((long)b * a.x.H + iy) * a.x.W + ix) * a.x.ld + cv * VEC);
       }
     }
-    stv<T>(yp + ((long)b * OHW + p) * a.y.ld + cv * VEC, pack<T>(o));
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long pp = p + (long)u * PL;
+      if (pp < p1) {
+        float o[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) o[e] = 0.f;
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+          float v[VEC]; unpack<T>(rx[u][k], v);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) o[e] += (RS == RS_DOWN ? 0.25f : 1.f) * silu_f<sizeof(T) == 4>(A[e] * (v[e] - mu[e]) + Bc[e]);
+        }
+        stv<T>(yp + ((long)b * OHW + pp) * a.y.ld + cv * VEC, pack<T>(o));
+      }
+    }
   }
 }
 
@@ -390,27 +394,40 @@ hipError_t launch_gn_fwd(const GNArgs& a0, hipStream_t s) {
 //   pass 1: per (b, chunk, c)  S1 = sum dv, S2 = sum dv * xhat              (reads x, dy; writes nothing else)
 //   pass 2: dx (+)= P dv + Q x + R                                          (reads x, dy; writes dx)
 // i.e. 4 tensor reads + 1 write instead of the 4 + 2 of a stored-dv formulation.
+template <typename T, int RS> struct DyRaw { V16 v[RS == RS_UP ? 4 : 1]; };
+// the raw dy vectors that feed pixel (y, x) of the x geometry (issued by the caller ahead of their use)
 template <typename T, int RS>
-__device__ __forceinline__ void gn_dv(const GNArgs& f, const TV& dy, int b, int y, int x, long p, int cv, const float* A, const float* Bc,
-                                      const float* mu, const float* xv, float keep, float inv_keep, float* dv) {
+__device__ __forceinline__ DyRaw<T, RS> gn_dy_load(const GNArgs& f, const TV& dy, int b, int y, int x, long p, int cv) {
   constexpr int VEC = ET<T>::VEC;
-  const int H = f.x.H, W = f.x.W, C = f.x.C;
+  const int H = f.x.H, W = f.x.W;
   const long HW = (long)H * W;
   const T* dyp = reinterpret_cast<const T*>(dy.p);
+  DyRaw<T, RS> r;
+  if (RS == RS_NONE) r.v[0] = ldv<T>(dyp + ((long)b * HW + p) * dy.ld + cv * VEC);
+  else if (RS == RS_DOWN) r.v[0] = ldv<T>(dyp + (((long)b * (H / 2) + (y >> 1)) * (W / 2) + (x >> 1)) * dy.ld + cv * VEC);
+  else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      r.v[q] = ldv<T>(dyp + (((long)b * (2 * H) + (2 * y + (q >> 1))) * (2 * W) + (2 * x + (q & 1))) * dy.ld + cv * VEC);
+  }
+  return r;
+}
+template <typename T, int RS>
+__device__ __forceinline__ void gn_dv_math(const GNArgs& f, const DyRaw<T, RS>& r, int b, long p, int cv, const float* A, const float* Bc,
+                                           const float* mu, const float* xv, float keep, float inv_keep, float* dv) {
+  constexpr int VEC = ET<T>::VEC;
+  const int C = f.x.C;
+  const long HW = (long)f.x.H * f.x.W;
   float dh[VEC];
-  if (RS == RS_NONE) {
-    unpack<T>(ldv<T>(dyp + ((long)b * HW + p) * dy.ld + cv * VEC), dh);
-  } else if (RS == RS_DOWN) {
-    unpack<T>(ldv<T>(dyp + (((long)b * (H / 2) + (y >> 1)) * (W / 2) + (x >> 1)) * dy.ld + cv * VEC), dh);
+  unpack<T>(r.v[0], dh);
+  if (RS == RS_DOWN) {
 #pragma unroll
     for (int e = 0; e < VEC; ++e) dh[e] *= 0.25f;
-  } else {
+  } else if (RS == RS_UP) {
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) dh[e] = 0.f;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 1; q < 4; ++q) {
       float t[VEC];
-      unpack<T>(ldv<T>(dyp + (((long)b * (2 * H) + (2 * y + (q >> 1))) * (2 * W) + (2 * x + (q & 1))) * dy.ld + cv * VEC), t);
+      unpack<T>(r.v[q], t);
 #pragma unroll
       for (int e = 0; e < VEC; ++e) dh[e] += t[e];
     }
@@ -486,13 +503,26 @@ __global__ __launch_bounds__(256) void gn_bwd_pass1_kernel(GNBwdArgs a) {
         }
       }
     } else {
-      for (long p = p0 + pl; p < p1; p += PL) {
-        const int y = (int)(p / W), x = (int)(p % W);
-        float xv[VEC], dv[VEC];
-        unpack<T>(ldv<T>(xp + ((long)b * HW + p) * f.x.ld + cv * VEC), xv);
-        gn_dv<T, RS>(f, a.dy, b, y, x, p, cv, A, Bc, mean, xv, keep, inv_keep, dv);
+      constexpr int U = RS == RS_UP ? 2 : 4;                        // pixels per trip, loads first (up: 5 vectors per pixel, down: 2)
+      for (long p = p0 + pl; p < p1; p += (long)PL * U) {
+        V16 rx[U]; DyRaw<T, RS> rd[U];
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) { s1[e] += dv[e]; s2[e] += dv[e] * (xv[e] - mean[e]) * rstd[e]; }
+        for (int u = 0; u < U; ++u) {
+          const long pp = p + (long)u * PL, q = pp < p1 ? pp : p;
+          rx[u] = ldv<T>(xp + ((long)b * HW + q) * f.x.ld + cv * VEC);
+          rd[u] = gn_dy_load<T, RS>(f, a.dy, b, (int)(q / W), (int)(q % W), q, cv);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const long pp = p + (long)u * PL;
+          if (pp < p1) {
+            float xv[VEC], dv[VEC];
+            unpack<T>(rx[u], xv);
+            gn_dv_math<T, RS>(f, rd[u], b, pp, cv, A, Bc, mean, xv, keep, inv_keep, dv);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) { s1[e] += dv[e]; s2[e] += dv[e] * (xv[e] - mean[e]) * rstd[e]; }
+          }
+        }
       }
     }
 #pragma unroll
@@ -636,19 +666,34 @@ __global__ __launch_bounds__(256) void gn_bwd_pass2_kernel(GNBwdArgs a) {
     }
     return;
   }
-  for (long p = p0 + pl; p < p1; p += PL) {
-    const long bp = (long)b * HW + p;
-    float xv[VEC], dv[VEC], o[VEC];
-    unpack<T>(ldv<T>(xp + bp * f.x.ld + cv * VEC), xv);
-    gn_dv<T, RS>(f, a.dy, b, (int)(p / W), (int)(p % W), p, cv, A, Bc, mu, xv, keep, inv_keep, dv);
-    if (a.accumulate) unpack<T>(ldv<T>(dxp + bp * a.dx.ld + cv * VEC), o);
-    else {
+  constexpr int U = RS == RS_UP ? 2 : 4;                            // pixels per trip, loads first
+  for (long p = p0 + pl; p < p1; p += (long)PL * U) {
+    V16 rx[U], ro[U]; DyRaw<T, RS> rd[U];
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) o[e] = 0.f;
+    for (int u = 0; u < U; ++u) {
+      const long pp = p + (long)u * PL, q = pp < p1 ? pp : p;
+      const long bq = (long)b * HW + q;
+      rx[u] = ldv<T>(xp + bq * f.x.ld + cv * VEC);
+      rd[u] = gn_dy_load<T, RS>(f, a.dy, b, (int)(q / W), (int)(q % W), q, cv);
+      if (a.accumulate) ro[u] = ldv<T>(dxp + bq * a.dx.ld + cv * VEC);
     }
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) o[e] += c0[e] * dv[e] + c1[e] * (xv[e] - mu[e]) + c2[e];
-    stv<T>(dxp + bp * a.dx.ld + cv * VEC, pack<T>(o));
+    for (int u = 0; u < U; ++u) {
+      const long pp = p + (long)u * PL;
+      if (pp < p1) {
+        float xv[VEC], dv[VEC], o[VEC];
+        unpack<T>(rx[u], xv);
+        gn_dv_math<T, RS>(f, rd[u], b, pp, cv, A, Bc, mu, xv, keep, inv_keep, dv);
+        if (a.accumulate) unpack<T>(ro[u], o);
+        else {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) o[e] = 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) o[e] += c0[e] * dv[e] + c1[e] * (xv[e] - mu[e]) + c2[e];
+        stv<T>(dxp + ((long)b * HW + pp) * a.dx.ld + cv * VEC, pack<T>(o));
+      }
+    }
   }
 }
 
@@ -699,20 +744,24 @@ __global__ __launch_bounds__(256) void gn_small_bwd_kernel(GNBwdArgs a, int CB) 
 #pragma unroll
     for (int e = 0; e < VEC; ++e) dv[e] = dh[e] * dsilu_f<false>(A[e] * (xv[e] - mu[e]) + Bc[e]);
   };
+  constexpr int U = 4;                                        // pixels per trip, every load issued before the first use
   if (act) {
-    for (long p = pl; p < HW; p += 2 * PL) {                  // two pixels per trip, loads first
-      const long p2 = p + PL;
-      const bool ok2 = p2 < HW;
-      const V16 rx0 = ldv<T>(xp + p * f.x.ld), rd0 = ldv<T>(dyp + p * a.dy.ld);
-      const V16 rx1 = ldv<T>(xp + (ok2 ? p2 : p) * f.x.ld), rd1 = ldv<T>(dyp + (ok2 ? p2 : p) * a.dy.ld);
-      float xv[VEC], dv[VEC];
-      dv_of(p, rx0, rd0, xv, dv);
+    for (long p = pl; p < HW; p += (long)U * PL) {
+      V16 rx[U], rd[U];
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) { s1[e] += dv[e]; s2[e] += dv[e] * (xv[e] - mu[e]) * rs[e]; }
-      if (ok2) {
-        dv_of(p2, rx1, rd1, xv, dv);
+      for (int u = 0; u < U; ++u) {
+        const long pp = p + (long)u * PL, q = pp < HW ? pp : p;
+        rx[u] = ldv<T>(xp + q * f.x.ld); rd[u] = ldv<T>(dyp + q * a.dy.ld);
+      }
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) { s1[e] += dv[e]; s2[e] += dv[e] * (xv[e] - mu[e]) * rs[e]; }
+      for (int u = 0; u < U; ++u) {
+        const long pp = p + (long)u * PL;
+        if (pp < HW) {
+          float xv[VEC], dv[VEC];
+          dv_of(pp, rx[u], rd[u], xv, dv);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) { s1[e] += dv[e]; s2[e] += dv[e] * (xv[e] - mu[e]) * rs[e]; }
+        }
       }
     }
   }
@@ -749,23 +798,36 @@ __global__ __launch_bounds__(256) void gn_small_bwd_kernel(GNBwdArgs a, int CB) 
   float o0[VEC], o1[VEC], o2[VEC];
 #pragma unroll
   for (int e = 0; e < VEC; ++e) { o0[e] = cof[(cv * VEC + e) * 3]; o1[e] = cof[(cv * VEC + e) * 3 + 1]; o2[e] = cof[(cv * VEC + e) * 3 + 2]; }
-  for (long p = pl; p < HW; p += PL) {
-    const V16 rx = ldv<T>(xp + p * f.x.ld), rd = ldv<T>(dyp + p * a.dy.ld);
-    float xv[VEC], dv[VEC], o[VEC];
-    if (a.accumulate) unpack<T>(ldv<T>(dxp + p * a.dx.ld), o);
-    else {
+  for (long p = pl; p < HW; p += (long)U * PL) {              // second read of x / dy (L2 hits), again four pixels per trip
+    V16 rx[U], rd[U], ro[U], ra[U];
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) o[e] = 0.f;
+    for (int u = 0; u < U; ++u) {
+      const long pp = p + (long)u * PL, q = pp < HW ? pp : p;
+      rx[u] = ldv<T>(xp + q * f.x.ld); rd[u] = ldv<T>(dyp + q * a.dy.ld);
+      if (a.accumulate) ro[u] = ldv<T>(dxp + q * a.dx.ld);
+      if (addp) ra[u] = ldv<T>(addp + q * a.add.ld);
     }
-    if (addp) {
-      float av[VEC]; unpack<T>(ldv<T>(addp + p * a.add.ld), av);
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) o[e] += av[e];
+    for (int u = 0; u < U; ++u) {
+      const long pp = p + (long)u * PL;
+      if (pp < HW) {
+        float xv[VEC], dv[VEC], o[VEC];
+        if (a.accumulate) unpack<T>(ro[u], o);
+        else {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) o[e] = 0.f;
+        }
+        if (addp) {
+          float av[VEC]; unpack<T>(ra[u], av);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) o[e] += av[e];
+        }
+        dv_of(pp, rx[u], rd[u], xv, dv);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) o[e] += o0[e] * dv[e] + o1[e] * (xv[e] - mu[e]) + o2[e];
+        stv<T>(dxp + pp * a.dx.ld, pack<T>(o));
+      }
     }
-    dv_of(p, rx, rd, xv, dv);
-#pragma unroll
-    for (int e = 0; e < VEC; ++e) o[e] += o0[e] * dv[e] + o1[e] * (xv[e] - mu[e]) + o2[e];
-    stv<T>(dxp + p * a.dx.ld, pack<T>(o));
   }
 }
 
