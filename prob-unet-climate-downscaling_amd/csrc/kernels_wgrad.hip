@@ -19,6 +19,16 @@
 
 #include "pu_kernels.h"
 
+// Diagnostic builds only (tools/ablate_wgrad.sh; results are WRONG by design): -DPU_WG_ABLATE=<bits> removes one ingredient of the main
+// kernel at a time - 1: one B fragment per K-step instead of one per tap (LDS read traffic 12 -> 4 reads per step), 2: no barrier in
+// the tile loop, 4: no global loads / LDS stores after the first tile, 8: no MFMAs, 16: no slab stores, 32: no global loads after the first tile (the LDS stores stay).
+#ifndef PU_WG_ABLATE
+#define PU_WG_ABLATE 0
+#endif
+#ifndef PU_WG_LATE_STORE
+#define PU_WG_LATE_STORE 0        // 1: the staged vectors of the next tile are written to LDS in one burst after the K-steps (first form)
+#endif
+
 namespace pu {
 
 typedef short s16x4v __attribute__((ext_vector_type(4)));
@@ -46,6 +56,7 @@ __device__ __forceinline__ Frag tr_frag(const uint16_t* p0, const uint16_t* p1) 
 template <typename T, int KS, int TH, int TW, int BCI, int NW, int BCO>
 __global__ __launch_bounds__(64 * NW) void conv_wgrad16_kernel(WgradArgs a) {
   typedef MMW<T> M;
+  constexpr bool LATE_STORE = PU_WG_LATE_STORE != 0;
   constexpr int NTH = 64 * NW;
   constexpr int TAPS = KS * KS, PADP = KS / 2;
   constexpr int BM = TH * TW;
@@ -109,23 +120,27 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad16_kernel(WgradArgs a) {
       }
     }
   };
-  auto lstore = [&](int buf) {
+  // one staged vector -> LDS: part p < NVD is a dy vector, the rest are halo-tile vectors
+  auto lstore_part = [&](int buf, int p) {
     uint16_t* sDy = lds + buf * BUF;
     uint16_t* sA = sDy + COS * BM * 32;
-#pragma unroll
-    for (int k = 0; k < NVD; ++k) {
-      const int i = tid + k * NTH;
+    if (p < NVD) {
+      const int i = tid + p * NTH;
       const int pix = i / (BCO / 8), cv = i % (BCO / 8);
-      if (i < NVD_TOT) *reinterpret_cast<V16*>(sDy + ((cv >> 2) * BM + pix) * 32 + (cv & 3) * 8) = rd[k];
-    }
-#pragma unroll
-    for (int k = 0; k < NVA; ++k) {
+      if (i < NVD_TOT) *reinterpret_cast<V16*>(sDy + ((cv >> 2) * BM + pix) * 32 + (cv & 3) * 8) = rd[p];
+    } else {
+      const int k = p - NVD;
       const int i = tid + k * NTH;
       if (i < NVA_TOT) {
         const int hp = i / (BCI / 8), cv = i % (BCI / 8);
         *reinterpret_cast<V16*>(sA + ((cv >> 2) * NPH + hp) * 32 + (cv & 3) * 8) = ra[k];
       }
     }
+  };
+  constexpr int NPARTS = NVD + NVA, STEPS = BM / 16;
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int p = 0; p < NPARTS; ++p) lstore_part(buf, p);
   };
 
   // lane roles of the transposed reads
@@ -143,7 +158,7 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad16_kernel(WgradArgs a) {
   __syncthreads();
   for (; tile < ntiles; tile += gridDim.x) {
     const int nxt = tile + gridDim.x;
-    if (nxt < ntiles) gload(nxt);
+    if (nxt < ntiles && !(PU_WG_ABLATE & (4 | 32))) gload(nxt);
     const uint16_t* sDy = lds + cur * BUF + (ct * BM) * 32 + cb;
     const uint16_t* sA = lds + cur * BUF + COS * BM * 32 + (it * NPH) * 32 + cb;
     // software-pipelined over the K-steps: the transposed reads of step kk+1 are issued as one block before the MFMAs of step
@@ -158,7 +173,8 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad16_kernel(WgradArgs a) {
         const int t = tap0 + j;
         const int tt = t < TAPS ? t : 0;
         const int toff = ((tt / KS) * IW + (tt % KS)) * 32;
-        fb[slot][j] = tr_frag<typename M::Frag>(sA + h0 + toff, sA + h1 + toff);
+        if ((PU_WG_ABLATE & 1) && j > 0) fb[slot][j] = fb[slot][0];
+        else fb[slot][j] = tr_frag<typename M::Frag>(sA + h0 + toff, sA + h1 + toff);
       }
     };
     load_step(0, 0);
@@ -168,7 +184,17 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad16_kernel(WgradArgs a) {
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < NJ; ++j)
-        if (tap0 + j < TAPS) acc[j] = M::mfma(fa[kk & 1], fb[kk & 1][j], acc[j]);
+        if (tap0 + j < TAPS) {
+          if (PU_WG_ABLATE & 8) acc[j][0] += (float)fa[kk & 1][0] * (float)fb[kk & 1][j][0];
+          else acc[j] = M::mfma(fa[kk & 1], fb[kk & 1][j], acc[j]);
+        }
+      // the next tile's staged vectors go to the other LDS buffer BETWEEN the MFMA groups of the last K-steps (ds_write issues beside
+      // the matrix pipe) instead of in one burst after them, when every wave of the block would be writing and none multiplying
+      if (!LATE_STORE && nxt < ntiles && !(PU_WG_ABLATE & 4)) {
+#pragma unroll
+        for (int p = 0; p < NPARTS; ++p)
+          if (STEPS - 1 - (NPARTS - 1 - p) * STEPS / NPARTS == kk) lstore_part(cur ^ 1, p);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     if (do_bias) {
@@ -180,9 +206,9 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad16_kernel(WgradArgs a) {
         bsum += ET<T>::ld(&v);
       }
     }
-    if (nxt < ntiles) lstore(cur ^ 1);
-    __syncthreads();
-    cur ^= 1;
+    if (LATE_STORE && nxt < ntiles && !(PU_WG_ABLATE & 4)) lstore(cur ^ 1);
+    if (!(PU_WG_ABLATE & 2)) __syncthreads();
+    if (!(PU_WG_ABLATE & 4)) cur ^= 1;
   }
   if (do_bias) {                                  // combine the pixel parts, one partial row per split
     float* red = reinterpret_cast<float*>(smem_raw);
@@ -204,7 +230,7 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad16_kernel(WgradArgs a) {
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int t = tap0 + j;
-    if (t < TAPS) {
+    if (t < TAPS && (!(PU_WG_ABLATE & 16) || acc[j][0] == 12345.f)) {
       const int ci = ci0 + it * 32 + (l & 31);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -487,7 +513,8 @@ hipError_t launch_wgrad16_reduce(const WgradReduce& r, hipStream_t s) {
 
 template <typename T, int KS>
 static hipError_t launch_wg16_ks(const WgradArgs& a, hipStream_t s, WgradReduce* red) {
-  const bool wide = a.Cin > 32;
+  static const bool wg_narrow = getenv("PU_WG_NARROW") != nullptr;   // diagnostic: 32-cin tiles, 4 waves, two blocks per CU for every layer
+  const bool wide = a.Cin > 32 && !wg_narrow;
   static const bool wg_big = getenv("PU_WG_BIG") != nullptr, wg_4w = getenv("PU_WG_4W") != nullptr;     // diagnostic switches, read once
   if (a.W % 32 == 0 && a.H % 8 == 0 && wide && wg_big) return launch_wg16<T, KS, 8, 32, 64>(a, s, red);   // 256-pixel K tiles: +4 % alone,
                                                                                             // but 152 KB LDS blocks co-residency with conv3
@@ -495,6 +522,9 @@ static hipError_t launch_wg16_ks(const WgradArgs& a, hipStream_t s, WgradReduce*
   if (a.W % 32 == 0 && a.H % 4 == 0 && a.Cout <= 32 && !no_bco32)      // 256 x 256 level: no zero-padded cout half; (cin sub-tile) x tap groups
     return wide ? launch_wg16<T, KS, 4, 32, 64, 4, 32>(a, s, red) : launch_wg16<T, KS, 4, 32, 32, 4, 32>(a, s, red);
   if (a.W % 32 == 0 && a.H % 4 == 0) return wide ? (wg_4w ? launch_wg16<T, KS, 4, 32, 64>(a, s, red) : launch_wg16<T, KS, 4, 32, 64, 8>(a, s, red)) : launch_wg16<T, KS, 4, 32, 32>(a, s, red);
+  // 16 x 16 level: 8 waves on 64-cin tiles.  32-cin tiles in 4-wave blocks (56 KB of LDS, two blocks per CU; PU_WG_NARROW=1) are 10-13 %
+  // faster in the micro-benchmark (64.6 / 119 us against 74.6 / 133 us at 512 -> 512 / 1024 -> 512) but not in the step, where the
+  // kernel shares the CUs with the main stream: 898.2 against 900.8 pairs/s, same box, alternating
   static const bool wg16_4w = getenv("PU_WG16_4W") != nullptr;
   if (a.W % 16 == 0 && a.H % 8 == 0) return wide ? (wg16_4w ? launch_wg16<T, KS, 8, 16, 64>(a, s, red) : launch_wg16<T, KS, 8, 16, 64, 8>(a, s, red)) : launch_wg16<T, KS, 8, 16, 32>(a, s, red);
   if (a.W % 8 == 0 && a.H % 8 == 0) return wide ? launch_wg16<T, KS, 8, 8, 64>(a, s, red) : launch_wg16<T, KS, 8, 8, 32>(a, s, red);
