@@ -26,7 +26,8 @@
 #define PU_WG_ABLATE 0
 #endif
 #ifndef PU_WG_LATE_STORE
-#define PU_WG_LATE_STORE 0        // 1: the staged vectors of the next tile are written to LDS in one burst after the K-steps (first form)
+#define PU_WG_LATE_STORE 1        // 1 (default): the staged vectors of the next tile are written to LDS in one burst after the K-steps;
+                                  // 0: between the MFMA groups of the last K-steps - measured neutral to 5 % slower (profiles/r2_ab_runs.txt)
 #endif
 
 namespace pu {
