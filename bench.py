@@ -256,8 +256,12 @@ def main():
     dev_index = 0 if rehearsal else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
-    if world > 1:
+    # PU_BENCH_FORCE_DIST=1 with one rank: a process group of ONE rank on the real backend (RCCL), the data-parallel path switched on -
+    # the only way to run communicator creation, the flat broadcast and the bucketed all-reduce against RCCL on a one-GPU box
+    force_dist = world == 1 and os.environ.get("PU_BENCH_FORCE_DIST") == "1"
+    if world > 1 or force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         if rehearsal:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -268,8 +272,8 @@ def main():
     model.dp_overlap_buckets = args.dp_buckets
     model.sync_scalars = False                       # keep the loss scalars on the device: no .item() sync per step
     torch.manual_seed(1234 + rank)                   # rank-offset reparameterisation noise (dropout seeds are rank-offset inside the model)
-    if world > 1:
-        model.enable_data_parallel()
+    if world > 1 or force_dist:
+        model.enable_data_parallel(single_rank_ok=force_dist)
     flat = not args.torch_adamw
     if flat:
         import probunet_amd as pa
@@ -368,9 +372,9 @@ def main():
                            elbo_fwd_bwd_tflop_per_step=round(3 * fwd_flops / 1e12, 3),
                            model_tflops=round(3 * fwd_flops * world / (elapsed / args.steps) / 1e12, 2),
                            beta_0=1.0, beta_1=args.beta1, final_loss=loss_val if loss_finite else None, loss_finite=loss_finite,
-                           world_size_seen_by_backend=(dist.get_world_size() if world > 1 else 1),
-                           backend=(dist.get_backend() if world > 1 else None),
-                           dp_gradient_buckets=(len(model._dp_bucket_ranges()) if world > 1 else 0)),
+                           world_size_seen_by_backend=(dist.get_world_size() if (world > 1 or force_dist) else 1),
+                           backend=(dist.get_backend() if (world > 1 or force_dist) else None),
+                           dp_gradient_buckets=(len(model._dp_bucket_ranges()) if (world > 1 or force_dist) else 0)),
                roofline=roofline)
     if rank == 0 and world == 1 and not args.no_secondary:
         # BASELINE config 5 beside the headline number (secondary metric): the training model is released first
@@ -384,7 +388,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(cfg)
     if rank == 0:
         print(json.dumps(out, allow_nan=False), flush=True)
-    if world > 1:
+    if world > 1 or force_dist:
         dist.destroy_process_group()
 
 

@@ -303,6 +303,7 @@ class ProbabilisticUNet(nn.Module):
         self._last_mu = {}
         self._dp_group = None
         self._dp_world = 1
+        self._dp_active = False           # gradients go through the process group (world > 1, or a single-rank group when asked for)
         self.dp_bucket_elems = 0
         self.dp_overlap_buckets = 4       # U-Net gradient buckets all-reduced under the rest of the backward (0: one all-reduce in backward())
         self._dp_works = None             # in-flight bucket collectives of the last fused elbo()
@@ -482,7 +483,7 @@ class ProbabilisticUNet(nn.Module):
         self._flatten(dev)
         L.check(L.lib().pu_bind_params(ctx, L.ptr(self._flat), L.ptr(self._engine_grads)), ctx, "pu_bind_params")
         L.lib().pu_set_sample_graph(ctx, 1 if self.use_sample_graph else 0)
-        if self._dp_world > 1 and self.dp_overlap_buckets > 0:
+        if self._dp_active and self.dp_overlap_buckets > 0:
             L.lib().pu_set_grad_buckets(ctx, int(self.dp_overlap_buckets))
         if self._drop_masks is not None:
             self._push_drop_masks()
@@ -550,7 +551,7 @@ class ProbabilisticUNet(nn.Module):
         views = self._grad_views(lo, hi)
         fresh = all(p.grad is None for p, _, _ in P[:4]) and P[-1][0].grad is None and P[len(P) // 2][0].grad is None
         fresh = fresh and all(p.grad is None for p, _, _ in P)
-        if self._dp_world > 1:
+        if self._dp_active:
             from .dp import allreduce_mean_
             # the 1 / world of the mean rides on the copy below when there is one (saves a pass over the 300 MB buffer)
             if self._dp_works is not None and lo == 0 and hi == self._nparams:
@@ -650,13 +651,16 @@ class ProbabilisticUNet(nn.Module):
         return r
 
     # ------------------------------------------------------------------ data parallel
-    def enable_data_parallel(self, process_group=None):
+    def enable_data_parallel(self, process_group=None, single_rank_ok=False):
         """One process per GPU; gradients are averaged with a torch.distributed all-reduce (backend 'nccl' == RCCL
-        over xGMI) on the flat gradient buffer before they reach p.grad.  Parameters are broadcast from rank 0."""
+        over xGMI) on the flat gradient buffer before they reach p.grad.  Parameters are broadcast from rank 0.
+        single_rank_ok: keep the collective path on even for a group of one rank (the RCCL smoke test of a one-GPU box:
+        communicator creation, the flat broadcast and the bucketed all-reduce behind the engine's events all run for real)."""
         import torch.distributed as dist
         self._dp_group = process_group
         self._dp_world = dist.get_world_size(process_group)
-        if self._dp_world > 1:
+        self._dp_active = self._dp_world > 1 or bool(single_rank_ok)
+        if self._dp_active:
             src = dist.get_global_rank(process_group, 0) if process_group is not None else 0
             dev = self._owner_device()
             if dev.type == "cuda":
@@ -819,7 +823,7 @@ class ProbabilisticUNet(nn.Module):
                 self._ctx, "pu_elbo_fwd_bwd")
         total = scal[L.PU_S_TOTAL]
         if with_bwd:
-            if self._dp_world > 1 and self.dp_overlap_buckets > 0:
+            if self._dp_active and self.dp_overlap_buckets > 0:
                 self._start_bucket_allreduce()            # enqueued now, runs under the rest of the backward on the GPU
             total = _DeliverGrads.apply(total, self._anchor_t(), self, 0, self._nparams)
         recon = scal[L.PU_S_RECON]

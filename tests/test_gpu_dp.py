@@ -125,3 +125,19 @@ def test_bench_self_launch_two_rank_rehearsal():
     assert out["n_gpus"] == 2 and out["config"]["world_size_seen_by_backend"] == 2 and out["config"]["backend"] == "gloo"
     assert out["config"]["dp_gradient_buckets"] >= 2 and out["config"]["loss_finite"] is True
     assert out["value"] > 0 and out["scaling"] == "weak" and out["config"]["global_batch"] == 4
+
+
+def test_bench_single_rank_rccl_path():
+    """The data-parallel path against the REAL backend on a one-GPU box: a process group of one rank on 'nccl' (= RCCL), the flat
+    broadcast, the bucketed all-reduce behind the engine's bucket events and the averaged delivery all run (PU_BENCH_FORCE_DIST=1).
+    A group of one makes the collectives identities, so the loss must stay finite and the line must report backend nccl."""
+    import json, subprocess
+    env = dict(os.environ, PU_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--batch", "4", "--members", "2",
+                        "--no-cpu-baseline", "--no-secondary"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["config"]["backend"] == "nccl" and out["config"]["world_size_seen_by_backend"] == 1
+    assert out["config"]["dp_gradient_buckets"] >= 2 and out["config"]["loss_finite"] is True and out["value"] > 0
