@@ -25,6 +25,10 @@
 #ifndef PU_WG_ABLATE
 #define PU_WG_ABLATE 0
 #endif
+#ifndef PU_WG_LATE_STORE
+#define PU_WG_LATE_STORE 1        // 1 (default): the staged vectors of the next tile are written to LDS in one burst after the K-steps;
+                                  // 0: between the MFMA groups of the last K-steps - measured neutral to 5 % slower (profiles/r2_ab_runs.txt)
+#endif
 
 namespace pu {
 
@@ -49,32 +53,11 @@ __device__ __forceinline__ Frag tr_frag(const uint16_t* p0, const uint16_t* p1) 
   return u.f;
 }
 
-__device__ __attribute__((aligned(16))) uint32_t g_wg_zero[4];      // what an out-of-image / out-of-range LDS-DMA lane reads
-typedef __attribute__((address_space(1))) const void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-__device__ __forceinline__ void wait_vmcnt(int n) {                    // counted wait (the count must be an immediate)
-  switch (n) {
-    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-  }
-}
-
 // BCO = couts per block (64, or 32 for the Cout <= 32 layers of the 256 x 256 level: half of a 64-cout tile would be zero padding)
-// GL = staging by LDS-DMA (global_load_lds_dwordx4) into THREE LDS buffers: the loads of tile t+2 are issued before the MFMAs of tile t
-// and retired by a counted s_waitcnt vmcnt(n) that leaves them in flight across the raw s_barrier ending tile t; no staging registers,
-// no ds_write.  The LDS image is the same [sub-tile][pixel][32 channels] (64-byte rows): 16 consecutive rows are the 1 KiB one
-// wave-instruction fills, lane -> (row = 16 * inst + lane / 4, 16-byte piece = lane % 4) picks its source address (zero page when
-// the row is outside the image or the channel range).
-template <typename T, int KS, int TH, int TW, int BCI, int NW, int BCO, bool GL = false>
+template <typename T, int KS, int TH, int TW, int BCI, int NW, int BCO>
 __global__ __launch_bounds__(64 * NW) void conv_wgrad16_kernel(WgradArgs a) {
   typedef MMW<T> M;
+  constexpr bool LATE_STORE = PU_WG_LATE_STORE != 0;
   constexpr int NTH = 64 * NW;
   constexpr int TAPS = KS * KS, PADP = KS / 2;
   constexpr int BM = TH * TW;
@@ -87,10 +70,6 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad16_kernel(WgradArgs a) {
   constexpr int NVA = (NVA_TOT + NTH - 1) / NTH;
   // wave roles: (cout sub-tile, cin sub-tile) x a tap group; the NW / (COS * CIS) tap groups split the taps evenly (two waves per
   // SIMD hide each other's LDS waits in the 8-wave forms; a group beyond the last tap only helps with the staging loads)
-  constexpr int ROWS = COS * BM + CIS * NPH;          // 64-byte rows of one buffer
-  constexpr int NINST = (ROWS + 15) / 16;             // LDS-DMA wave-instructions per tile
-  constexpr int NI = (NINST + NW - 1) / NW;           // ... per wave (at most)
-  constexpr int BUFS = GL ? NINST * 16 * 32 : BUF;    // elements between two buffers
   constexpr int GROUPS = NW / (COS * CIS);
   constexpr int NJ = (TAPS + GROUPS - 1) / GROUPS;
   static_assert(NW % (COS * CIS) == 0 && GROUPS >= 1, "wave roles");
@@ -114,43 +93,7 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad16_kernel(WgradArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-  // ---- LDS-DMA staging (GL)
-  const int my_n = (NINST - wave + NW - 1) / NW;      // instructions this wave issues per tile
-  const unsigned lds_base = (unsigned)(uintptr_t)(lptr_t)smem_raw;
-  auto issue = [&](int tile, int buf) {
-    int pt = tile;
-    const int tx0 = (pt % tiles_x) * TW; pt /= tiles_x;
-    const int ty0 = (pt % tiles_y) * TH; pt /= tiles_y;
-    const int b = pt;
-#pragma unroll
-    for (int k = 0; k < NI; ++k) {
-      const int inst = wave + k * NW;
-      if (inst < NINST) {
-        const int row = inst * 16 + (l >> 2), cvl = l & 3;
-        const uint16_t* src = reinterpret_cast<const uint16_t*>(g_wg_zero);
-        if (row < COS * BM) {
-          const int sb = row / BM, pix = row % BM;
-          const int gy = ty0 + pix / TW, gx = tx0 + pix % TW;
-          const int co = co0 + sb * 32 + cvl * 8;
-          if (co < a.Cout) src = dy + ((size_t)(b * a.H + gy) * a.W + gx) * a.dy_ld + co;
-        } else if (row < ROWS) {
-          const int r2 = row - COS * BM;
-          const int sb = r2 / NPH, hp = r2 % NPH;
-          const int gy = ty0 + hp / IW - PADP, gx = tx0 + hp % IW - PADP;
-          const int ci = ci0 + sb * 32 + cvl * 8;
-          if (gy >= 0 && gy < a.H && gx >= 0 && gx < a.W && ci < a.Cin) src = in + ((size_t)(b * a.H + gy) * a.W + gx) * a.in_ld + ci;
-        }
-        // inline asm, not __builtin_amdgcn_global_load_lds: hipcc puts s_waitcnt vmcnt(0) in front of the first ds_read after a
-        // builtin LDS-DMA load (it cannot tell which LDS bytes the load writes), which would retire the tile just issued
-        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)((buf * BUFS + inst * 16 * 32) * 2));
-        unsigned keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
-      }
-    }
-  };
-
-  V16 rd[GL ? 1 : NVD], ra[GL ? 1 : NVA];
+  V16 rd[NVD], ra[NVA];
   auto gload = [&](int tile) {
     int pt = tile;
     const int tx0 = (pt % tiles_x) * TW; pt /= tiles_x;
@@ -195,7 +138,7 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad16_kernel(WgradArgs a) {
       }
     }
   };
-  constexpr int NPARTS = NVD + NVA;
+  constexpr int NPARTS = NVD + NVA, STEPS = BM / 16;
   auto lstore = [&](int buf) {
 #pragma unroll
     for (int p = 0; p < NPARTS; ++p) lstore_part(buf, p);
@@ -210,10 +153,15 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad16_kernel(WgradArgs a) {
   const bool do_bias = a.dbias0 != nullptr && blockIdx.z == 0;
   float bsum = 0.f;
 
-  // the MFMA part of one tile out of LDS buffer `cur` (+ the fused bias column sums)
-  auto compute = [&](int cur) {
-    const uint16_t* sDy = lds + cur * BUFS + (ct * BM) * 32 + cb;
-    const uint16_t* sA = lds + cur * BUFS + COS * BM * 32 + (it * NPH) * 32 + cb;
+  int tile = blockIdx.x;
+  int cur = 0;
+  if (tile < ntiles) { gload(tile); lstore(0); }
+  __syncthreads();
+  for (; tile < ntiles; tile += gridDim.x) {
+    const int nxt = tile + gridDim.x;
+    if (nxt < ntiles && !(PU_WG_ABLATE & (4 | 32))) gload(nxt);
+    const uint16_t* sDy = lds + cur * BUF + (ct * BM) * 32 + cb;
+    const uint16_t* sA = lds + cur * BUF + COS * BM * 32 + (it * NPH) * 32 + cb;
     // software-pipelined over the K-steps: the transposed reads of step kk+1 are issued as one block before the MFMAs of step
     // kk (sched_barrier keeps the blocks apart), so they land under those MFMAs instead of stalling their own consumers
     typename M::Frag fa[2], fb[2][NJ];
@@ -241,48 +189,27 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad16_kernel(WgradArgs a) {
           if (PU_WG_ABLATE & 8) acc[j][0] += (float)fa[kk & 1][0] * (float)fb[kk & 1][j][0];
           else acc[j] = M::mfma(fa[kk & 1], fb[kk & 1][j], acc[j]);
         }
+      // the next tile's staged vectors go to the other LDS buffer BETWEEN the MFMA groups of the last K-steps (ds_write issues beside
+      // the matrix pipe) instead of in one burst after them, when every wave of the block would be writing and none multiplying
+      if (!LATE_STORE && nxt < ntiles && !(PU_WG_ABLATE & 4)) {
+#pragma unroll
+        for (int p = 0; p < NPARTS; ++p)
+          if (STEPS - 1 - (NPARTS - 1 - p) * STEPS / NPARTS == kk) lstore_part(cur ^ 1, p);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     if (do_bias) {
       const int bc = tid % BCO, bp = tid / BCO;
-      const uint16_t* col = lds + cur * BUFS + ((bc >> 5) * BM) * 32 + (bc & 31);
+      const uint16_t* col = lds + cur * BUF + ((bc >> 5) * BM) * 32 + (bc & 31);
 #pragma unroll 8
       for (int pp = bp * (BM / BPARTS); pp < (bp + 1) * (BM / BPARTS); ++pp) {
         T v; *reinterpret_cast<uint16_t*>(&v) = col[pp * 32];
         bsum += ET<T>::ld(&v);
       }
     }
-  };
-
-  int tile = blockIdx.x;
-  int cur = 0;
-  if constexpr (GL) {
-    // prologue: tiles t and t + stride in flight, the first one retired
-    const int stride = gridDim.x;
-    if (tile < ntiles) issue(tile, 0);
-    if (tile + stride < ntiles) { issue(tile + stride, 1); wait_vmcnt(my_n); } else wait_vmcnt(0);
-    __builtin_amdgcn_s_barrier();
-    for (; tile < ntiles; tile += stride) {
-      const bool more = tile + 2 * stride < ntiles;
-      if (more) issue(tile + 2 * stride, cur >= 1 ? cur - 1 : 2);          // (cur + 2) % 3: the buffer read one tile ago
-      compute(cur);
-      // retire tile t + 1 (issued one trip ago), leave tile t + 2 in flight across the barrier; this wave's LDS reads of `cur` are done
-      if (more) wait_vmcnt(my_n); else wait_vmcnt(0);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      cur = cur == 2 ? 0 : cur + 1;
-    }
-  } else {
-    if (tile < ntiles) { gload(tile); lstore(0); }
-    __syncthreads();
-    for (; tile < ntiles; tile += gridDim.x) {
-      const int nxt = tile + gridDim.x;
-      if (nxt < ntiles && !(PU_WG_ABLATE & (4 | 32))) gload(nxt);
-      compute(cur);
-      if (nxt < ntiles && !(PU_WG_ABLATE & 4)) lstore(cur ^ 1);
-      if (!(PU_WG_ABLATE & 2)) __syncthreads();
-      if (!(PU_WG_ABLATE & 4)) cur ^= 1;
-    }
+    if (LATE_STORE && nxt < ntiles && !(PU_WG_ABLATE & 4)) lstore(cur ^ 1);
+    if (!(PU_WG_ABLATE & 2)) __syncthreads();
+    if (!(PU_WG_ABLATE & 4)) cur ^= 1;
   }
   if (do_bias) {                                  // combine the pixel parts, one partial row per split
     float* red = reinterpret_cast<float*>(smem_raw);
@@ -379,13 +306,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
-template <typename T, int KS, int TH, int TW, int BCI, int NW = 4, int WBCO = 64, bool GL = false>
+template <typename T, int KS, int TH, int TW, int BCI, int NW = 4, int WBCO = 64>
 static hipError_t launch_wg16(const WgradArgs& a, hipStream_t s, WgradReduce* red) {
   constexpr int PADP = KS / 2, BM = TH * TW, NPH = (TH + 2 * PADP) * (TW + 2 * PADP), TAPS = KS * KS;
-  constexpr int ROWS = (WBCO / 32) * BM + (BCI / 32) * NPH;
-  constexpr size_t lds_tiles = GL ? (size_t)3 * ((ROWS + 15) / 16) * 16 * 32 * 2 : (size_t)2 * ROWS * 32 * 2;
+  constexpr size_t lds_tiles = (size_t)2 * ((WBCO / 32) * BM + (BCI / 32) * NPH) * 32 * 2;
   constexpr size_t lds = lds_tiles > (size_t)64 * NW * 4 ? lds_tiles : (size_t)64 * NW * 4;     // the bias combine reuses the buffer
-  auto kern = conv_wgrad16_kernel<T, KS, TH, TW, BCI, NW, WBCO, GL>;
+  auto kern = conv_wgrad16_kernel<T, KS, TH, TW, BCI, NW, WBCO>;
   static AttrOnce attr_once;
   if (!attr_once.cur()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -404,7 +330,7 @@ static hipError_t launch_wg16(const WgradArgs& a, hipStream_t s, WgradReduce* re
   char tag[128];
   const bool prof = prof_enabled();
   if (prof) {
-    snprintf(tag, sizeof tag, "conv_wgrad16_kernel<%s,%d,%d,%d,%d,%d,%d%s>", ET<T>::DT == 1 ? "f16" : "bf16", KS, TH, TW, BCI, NW, WBCO, GL ? ",dma" : "");
+    snprintf(tag, sizeof tag, "conv_wgrad16_kernel<%s,%d,%d,%d,%d,%d,%d>", ET<T>::DT == 1 ? "f16" : "bf16", KS, TH, TW, BCI, NW, WBCO);
     const double px = (double)a.B * a.H * a.W;
     prof_record(tag, 2.0 * px * a.Cout * (double)a.Cin * a.taps, px * (a.Cin + a.Cout) * 2 + (double)a.Cout * a.Cin * a.taps * 4, s, true);
   }
@@ -596,14 +522,11 @@ static hipError_t launch_wg16_ks(const WgradArgs& a, hipStream_t s, WgradReduce*
   static const bool no_bco32 = getenv("PU_WG_NO_BCO32") != nullptr;
   if (a.W % 32 == 0 && a.H % 4 == 0 && a.Cout <= 32 && !no_bco32)      // 256 x 256 level: no zero-padded cout half; (cin sub-tile) x tap groups
     return wide ? launch_wg16<T, KS, 4, 32, 64, 4, 32>(a, s, red) : launch_wg16<T, KS, 4, 32, 32, 4, 32>(a, s, red);
-  static const bool wg_glds = getenv("PU_WG_GLDS") != nullptr;       // LDS-DMA staging, three LDS buffers (8-wave 64 x 64 tiles)
-  if (a.W % 32 == 0 && a.H % 4 == 0 && wide && wg_glds && !wg_4w) return launch_wg16<T, KS, 4, 32, 64, 8, 64, true>(a, s, red);
   if (a.W % 32 == 0 && a.H % 4 == 0) return wide ? (wg_4w ? launch_wg16<T, KS, 4, 32, 64>(a, s, red) : launch_wg16<T, KS, 4, 32, 64, 8>(a, s, red)) : launch_wg16<T, KS, 4, 32, 32>(a, s, red);
   // 16 x 16 level: 8 waves on 64-cin tiles.  32-cin tiles in 4-wave blocks (56 KB of LDS, two blocks per CU; PU_WG_NARROW=1) are 10-13 %
   // faster in the micro-benchmark (64.6 / 119 us against 74.6 / 133 us at 512 -> 512 / 1024 -> 512) but not in the step, where the
   // kernel shares the CUs with the main stream: 898.2 against 900.8 pairs/s, same box, alternating
   static const bool wg16_4w = getenv("PU_WG16_4W") != nullptr;
-  if (a.W % 16 == 0 && a.H % 8 == 0 && wide && wg_glds && !wg16_4w) return launch_wg16<T, KS, 8, 16, 64, 8, 64, true>(a, s, red);
   if (a.W % 16 == 0 && a.H % 8 == 0) return wide ? (wg16_4w ? launch_wg16<T, KS, 8, 16, 64>(a, s, red) : launch_wg16<T, KS, 8, 16, 64, 8>(a, s, red)) : launch_wg16<T, KS, 8, 16, 32>(a, s, red);
   if (a.W % 8 == 0 && a.H % 8 == 0) return wide ? launch_wg16<T, KS, 8, 8, 64>(a, s, red) : launch_wg16<T, KS, 8, 8, 32>(a, s, red);
   return hipErrorInvalidValue;
