@@ -30,7 +30,8 @@ def q(t, dt):
 @pytest.mark.parametrize("dt", DT)
 @pytest.mark.parametrize("shape", [(2, 8, 16, 32, 32, 3), (1, 4, 32, 32, 64, 3), (2, 48, 24, 16, 16, 3), (3, 32, 64, 8, 8, 3),
                                    (2, 96, 32, 16, 32, 3), (2, 40, 16, 32, 32, 1), (1, 64, 128, 8, 8, 1), (1, 5, 8, 16, 16, 3),
-                                   (1, 96, 128, 8, 32, 3), (1, 160, 96, 8, 64, 3)])      # K > 64, Cout > 64, 32-wide: the dominant conv3 class
+                                   (1, 96, 128, 8, 32, 3), (1, 160, 96, 8, 64, 3),       # K > 64, Cout > 64, 32-wide: the dominant conv3 class
+                                   (1, 512, 512, 16, 16, 3), (2, 256, 256, 32, 32, 3)])   # large dw: the all-taps units of the slab reduction (4 and 16 split lanes)
 def test_conv_fwd_dgrad_wgrad(dt, shape):
     B, Cin, Cout, H, W, ks = shape
     dev = torch.device("cuda:0"); g = torch.Generator(device="cpu").manual_seed(B * 1000 + Cin * 10 + Cout + H)
