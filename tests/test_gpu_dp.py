@@ -131,8 +131,10 @@ def test_bench_single_rank_rccl_path():
     """The data-parallel path against the REAL backend on a one-GPU box: a process group of one rank on 'nccl' (= RCCL), the flat
     broadcast, the bucketed all-reduce behind the engine's bucket events and the averaged delivery all run (PU_BENCH_FORCE_DIST=1).
     A group of one makes the collectives identities, so the loss must stay finite and the line must report backend nccl."""
-    import json, subprocess
-    env = dict(os.environ, PU_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+    import json, socket, subprocess
+    with socket.socket() as sk:                                    # a free rendezvous port
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    env = dict(os.environ, PU_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--batch", "4", "--members", "2",
