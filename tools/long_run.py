@@ -1,4 +1,4 @@
-import sys; sys.path.insert(0, '/root/repo')
+import sys; import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, bench
 import probunet_amd as pa
 dev = torch.device('cuda', 0)
