@@ -235,6 +235,8 @@ def main():
     ap.add_argument("--beta1", type=float, default=0.0,
                     help="KL weight; 0 = the reference's first-epoch setting (main.py:109-110). The work per step does not depend on it")
     ap.add_argument("--dp-buckets", type=int, default=4, help="N > 1: U-Net gradient buckets all-reduced under the backward (0 = one all-reduce)")
+    ap.add_argument("--dp-wire", default="f32", choices=["f32", "bf16"],
+                    help="N > 1: element type of the gradient all-reduce (bf16 = optional compression, half the bytes; default f32)")
     ap.add_argument("--recon", default="afcrps", choices=["afcrps", "wmse_msssim", "l1"],
                     help="reconstruction term; afcrps is the reported metric, wmse_msssim is the reference's live elbo (diagnostic)")
     args = ap.parse_args()
@@ -270,6 +272,7 @@ def main():
     cfg = dict(CFG3, batch=args.batch, M=args.members)
     model = build_model(cfg, args.dtype, device, args.recon, args.beta1)
     model.dp_overlap_buckets = args.dp_buckets
+    model.dp_wire_dtype = None if args.dp_wire == "f32" else args.dp_wire
     model.sync_scalars = False                       # keep the loss scalars on the device: no .item() sync per step
     torch.manual_seed(1234 + rank)                   # rank-offset reparameterisation noise (dropout seeds are rank-offset inside the model)
     if world > 1 or force_dist:
@@ -374,7 +377,8 @@ def main():
                            beta_0=1.0, beta_1=args.beta1, final_loss=loss_val if loss_finite else None, loss_finite=loss_finite,
                            world_size_seen_by_backend=(dist.get_world_size() if (world > 1 or force_dist) else 1),
                            backend=(dist.get_backend() if (world > 1 or force_dist) else None),
-                           dp_gradient_buckets=(len(model._dp_bucket_ranges()) if (world > 1 or force_dist) else 0)),
+                           dp_gradient_buckets=(len(model._dp_bucket_ranges()) if (world > 1 or force_dist) else 0),
+                           dp_wire_dtype=(args.dp_wire if (world > 1 or force_dist) else None)),
                roofline=roofline)
     if rank == 0 and world == 1 and not args.no_secondary:
         # BASELINE config 5 beside the headline number (secondary metric): the training model is released first

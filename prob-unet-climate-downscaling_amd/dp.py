@@ -31,20 +31,26 @@ def init_from_env(backend: Optional[str] = None):
     return rank, local_rank, world
 
 
-def allreduce_mean_(flat: torch.Tensor, group=None, bucket_elems: int = 0, average: bool = True) -> torch.Tensor:
+def allreduce_mean_(flat: torch.Tensor, group=None, bucket_elems: int = 0, average: bool = True,
+                    wire_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
     """In-place mean over the process group of a flat gradient buffer.  bucket_elems > 0 splits the reduction into
     buckets of that many elements (point-to-point xGMI rings are per-link bound, so a few large buckets are best);
-    0 = one collective.  average=False leaves the SUM in place (the caller folds 1 / world into a pass it makes anyway)."""
+    0 = one collective.  average=False leaves the SUM in place (the caller folds 1 / world into a pass it makes anyway).
+    wire_dtype (e.g. torch.bfloat16): the optional gradient compression of SURVEY.md §8e - the buffer is cast to that type for
+    the collective and the reduced values are written back in fp32 (half the bytes on the wire, ~3 significant digits)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         return flat
-    if bucket_elems <= 0 or bucket_elems >= flat.numel():
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    wire = flat if wire_dtype is None or wire_dtype == flat.dtype else flat.to(wire_dtype)
+    if bucket_elems <= 0 or bucket_elems >= wire.numel():
+        dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=group)
     else:
-        works = [dist.all_reduce(flat[i:i + bucket_elems], op=dist.ReduceOp.SUM, group=group, async_op=True)
-                 for i in range(0, flat.numel(), bucket_elems)]
+        works = [dist.all_reduce(wire[i:i + bucket_elems], op=dist.ReduceOp.SUM, group=group, async_op=True)
+                 for i in range(0, wire.numel(), bucket_elems)]
         for w in works:
             w.wait()
+    if wire is not flat:
+        flat.copy_(wire)
     if average:
         flat.mul_(1.0 / world)
     return flat

@@ -307,6 +307,8 @@ class ProbabilisticUNet(nn.Module):
         self.dp_bucket_elems = 0
         self.dp_overlap_buckets = 4       # U-Net gradient buckets all-reduced under the rest of the backward (0: one all-reduce in backward())
         self._dp_works = None             # in-flight bucket collectives of the last fused elbo()
+        self.dp_wire_dtype = None         # None: fp32 all-reduce (default); "bf16": gradients cross the wire as bfloat16 (optional compression)
+        self._dp_wire = None              # persistent bf16 staging buffer of that mode
         self._comm_stream = None
         self.use_sample_graph = True      # cfg5: pu_sample / pu_sample_hr launch sequences are captured in a hipGraph and replayed
         # one forward in flight per engine: every entry that overwrites saved engine state bumps its generation; backward checks it
@@ -559,7 +561,7 @@ class ProbabilisticUNet(nn.Module):
                 if not fresh:
                     eg.mul_(1.0 / self._dp_world)
             else:
-                allreduce_mean_(eg, self._dp_group, self.dp_bucket_elems, average=not fresh)
+                allreduce_mean_(eg, self._dp_group, self.dp_bucket_elems, average=not fresh, wire_dtype=self._wire_dtype())
             # an overflow on ANY rank makes the SUM non-finite on EVERY rank (inf + x = inf, inf - inf = NaN): the optimizer derives
             # its skip flag from the averaged buffer (FlatAdamW.step), so all ranks skip together without another collective
             if fresh:
@@ -597,10 +599,19 @@ class ProbabilisticUNet(nn.Module):
             self._comm_stream = torch.cuda.Stream(device=dev)
         cs = self._comm_stream
         works = []
+        wd = self._wire_dtype()
+        if wd is not None and (self._dp_wire is None or self._dp_wire.numel() != self._engine_grads.numel() or self._dp_wire.device != dev):
+            self._dp_wire = torch.empty(self._engine_grads.numel(), dtype=wd, device=dev)      # persistent: used on the comm streams
         with torch.cuda.stream(cs):
             for k in range(n.value):
                 L.check(lib.pu_grad_bucket_wait(self._ctx, k, C.c_void_p(cs.cuda_stream)), self._ctx, "pu_grad_bucket_wait")
-                works.append(dist.all_reduce(self._engine_grads[lo[k]:hi[k]], op=dist.ReduceOp.SUM, group=self._dp_group, async_op=True))
+                seg = self._engine_grads[lo[k]:hi[k]]
+                if wd is not None:                      # compress on the comm stream, behind the bucket's events
+                    wire = self._dp_wire[lo[k]:hi[k]]
+                    wire.copy_(seg)
+                    works.append((dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self._dp_group, async_op=True), seg, wire))
+                else:
+                    works.append((dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self._dp_group, async_op=True), None, None))
         self._dp_works = works
 
     def _dp_bucket_ranges(self):
@@ -612,9 +623,18 @@ class ProbabilisticUNet(nn.Module):
 
     def _finish_dp_works(self):
         if self._dp_works is not None:
-            for w in self._dp_works:
+            for w, seg, wire in self._dp_works:
                 w.wait()                                  # the current stream waits for the collective's stream (no host sync with RCCL)
+                if wire is not None:
+                    seg.copy_(wire)                       # reduced bf16 values back into the fp32 gradient buffer
             self._dp_works = None
+
+    def _wire_dtype(self):
+        if self.dp_wire_dtype in (None, "", "f32", "fp32", torch.float32):
+            return None
+        if self.dp_wire_dtype in ("bf16", "bfloat16", torch.bfloat16):
+            return torch.bfloat16
+        raise ValueError(f"dp_wire_dtype must be None or 'bf16', got {self.dp_wire_dtype!r}")
 
     def _grad_views(self, lo, hi):
         key = ("gv", lo, hi, self._flat_grad.data_ptr())

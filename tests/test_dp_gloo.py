@@ -29,6 +29,10 @@ def _worker(rank, world, initfile, out):
     flat2 = torch.cat([g[k].reshape(-1) for k in names])
     pa.dp.allreduce_mean_(flat2)                                    # single collective
     assert torch.allclose(flat, flat2, rtol=0, atol=0)
+    flat3 = torch.cat([g[k].reshape(-1) for k in names])
+    pa.dp.allreduce_mean_(flat3, None, bucket_elems=10_000, wire_dtype=torch.bfloat16)     # optional bf16 wire compression
+    assert flat3.dtype == torch.float32
+    assert float((flat3 - flat).abs().max()) <= 1e-2 * float(flat.abs().max()) and not torch.equal(flat3, flat)
     assert pa.dp.rank_seed(7, rank) != pa.dp.rank_seed(7, 1 - rank)
     if rank == 0:
         _, gg = O.elbo_with_grads(P, cfg, x, y, eps, beta0=0.7, beta1=1.3)
