@@ -1,5 +1,7 @@
 """Per-shape event timing of the GroupNorm kernels inside one serial cfg3 step (PU_PROF_GN=1 makes launch_gn_fwd / launch_gn_bwd
-record HIP events per launch, tagged with kernel, resample mode and tensor shape).  usage: PU_PROF_GN=1 python tools/gn_profile.py"""
+record HIP events per launch, tagged with kernel, resample mode, tensor shape, strides and flags).  Use it for the POPULATION of GroupNorm
+launches (which shapes, how many, with which flags); the durations are inflated by the per-launch event creation on the host (14.2 ms
+summed here against 9.7 ms in the rocprof trace) - time a shape with tools/gn_microbench.py.  usage: PU_PROF_GN=1 python tools/gn_profile.py"""
 import os, sys
 os.environ.setdefault("PU_PROF_GN", "1")
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
