@@ -167,6 +167,12 @@ int pu_sample_hr(pu_ctx*, const float* x, const float* target_or_null, const flo
  *      the LAST member's WMSE and (1 - MS-SSIM), which is what the reference returns for logging.  Requires H, W > 96.
  *      MS-SSIM restates pytorch-msssim 1.0.0 (absent from this image): parity unpinned, see oracle/probunet_oracle.py. */
 int pu_set_recon_wmse_msssim(pu_ctx*, float alpha_w, float beta_w, float lam_w, float data_range);
+/* Value range of the WMSE-MS-SSIM term taken from a DEVICE float (read when the loss kernels run, clamped to >= 1e-5) instead of the
+ * data_range argument above or the on-device inference from the local target; null restores those.  Used under data parallelism: the
+ * reference infers max(target) - min(target) over the batch it sees (prob_unet_utils.py:288-289), so ranks exchange their minima and
+ * maxima (two scalar all-reduces on the device) and hand the global range in here without a host round trip.  The pointer must stay
+ * valid until the call that uses it has run. */
+int pu_set_recon_range_dev(pu_ctx*, const float* range_dev_or_null);
 
 /* ---- ClimEx-shaped data transforms on the device (climex_utils.py:197-225, :255-264); all pointers device fp32 NCHW ----
  * pu_lr_stats: mean / unbiased std over the N items of the k x k block means (AvgPool2d(k)); *_lr are [C,H/k,W/k],

@@ -74,6 +74,7 @@ def lib():
     L.pu_sample_hr.restype = i32
     L.pu_sample_hr.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp, f32, i32, f32, vp, vp, vp, vp]
     L.pu_set_recon_wmse_msssim.restype = i32; L.pu_set_recon_wmse_msssim.argtypes = [vp, f32, f32, f32, f32]
+    L.pu_set_recon_range_dev.restype = i32; L.pu_set_recon_range_dev.argtypes = [vp, vp]
     L.pu_lr_stats.restype = i32; L.pu_lr_stats.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp, vp]
     L.pu_lrinterp_to_residuals.restype = i32
     L.pu_lrinterp_to_residuals.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, f32, vp, vp, vp, vp, vp]

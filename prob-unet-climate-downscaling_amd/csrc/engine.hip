@@ -87,6 +87,7 @@ struct pu_ctx {
   // weight-gradient kernels (MFMA-bound) run on a side stream, overlapping the HBM-bound dgrad -> GroupNorm-backward chain
   bool fused_stats = true;
   float wm_alpha = 0.007f, wm_beta = 0.048f, wm_lam = 0.f, wm_range = -1.f;     // wmse_ms_ssim_loss defaults (prob_unet.py:231-233)
+  const float* wm_range_dev = nullptr;                                           // pu_set_recon_range_dev
   float* ms_ws = nullptr; size_t ms_ws_floats = 0;                              // MS-SSIM pyramid workspace, allocated on first use
   static constexpr int NSLAB = 1;
   hipStream_t side = nullptr, side2 = nullptr; std::vector<hipEvent_t> evs; size_t ev_next = 0; bool side_dirty = false; bool use_side = true;
@@ -1060,7 +1061,7 @@ int pu_elbo_fwd_bwd(pu_ctx* c, const float* x, const float* target, const float*
     if (msssim) {
       MsssimArgs ma; memset(&ma, 0, sizeof ma);
       ma.pred = c->preds; ma.target = target; ma.B = B; ma.M = Mf; ma.C = Co; ma.H = cf.H; ma.W = cf.W;
-      ma.alpha_w = c->wm_alpha; ma.beta_w = c->wm_beta; ma.lam_w = c->wm_lam; ma.data_range = c->wm_range; ma.gscale = beta0 * S;
+      ma.alpha_w = c->wm_alpha; ma.beta_w = c->wm_beta; ma.lam_w = c->wm_lam; ma.data_range = c->wm_range; ma.data_range_dev = c->wm_range_dev; ma.gscale = beta0 * S;
       ma.ws = c->ms_ws; ma.ws_floats = c->ms_ws_floats; ma.scalars = c->scal; ma.dpred = with_backward ? c->dpreds : nullptr;
       CKH(launch_wmse_msssim(ma, s));
     } else
@@ -1269,6 +1270,11 @@ int pu_destandardize(const float* x, const float* base, const float* std_hr, con
 int pu_set_recon_wmse_msssim(pu_ctx* c, float alpha_w, float beta_w, float lam_w, float data_range) {
   if (!c) return PU_ERR_INVALID;
   c->wm_alpha = alpha_w; c->wm_beta = beta_w; c->wm_lam = lam_w; c->wm_range = data_range;
+  return PU_OK;
+}
+int pu_set_recon_range_dev(pu_ctx* c, const float* range_dev) {
+  if (!c) return PU_ERR_INVALID;
+  c->wm_range_dev = range_dev;
   return PU_OK;
 }
 int pu_lr_stats(const float* hr, int N, int C, int H, int W, int k, float* mean_lr, float* std_lr, float* mean_hr, float* std_hr, void* stream) {

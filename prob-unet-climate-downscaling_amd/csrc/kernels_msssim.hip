@@ -47,8 +47,10 @@ __global__ __launch_bounds__(256) void ms_range_partial_kernel(const float* __re
     part[blockIdx.x * 2 + 1] = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
   }
 }
-__global__ __launch_bounds__(256) void ms_range_final_kernel(const float* __restrict__ part, int nblk, float fixed, float* __restrict__ dr) {
+__global__ __launch_bounds__(256) void ms_range_final_kernel(const float* __restrict__ part, int nblk, float fixed, const float* __restrict__ fixed_dev,
+                                                             float* __restrict__ dr) {
   __shared__ float smn[4], smx[4];
+  if (fixed_dev) { if (threadIdx.x == 0) dr[0] = fmaxf(fixed_dev[0], 1e-5f); return; }      // range decided by the caller on the device
   if (fixed > 0.f) { if (threadIdx.x == 0) dr[0] = fixed; return; }
   float mn = INFINITY, mx = -INFINITY;
   for (int i = threadIdx.x; i < nblk; i += 256) { mn = fminf(mn, part[i * 2]); mx = fmaxf(mx, part[i * 2 + 1]); }
@@ -346,8 +348,9 @@ hipError_t launch_wmse_msssim(const MsssimArgs& a, hipStream_t s) {
   }
   float* gco = p; p += (size_t)NC * NLV;
 
-  if (a.data_range <= 0.f) hipLaunchKernelGGL(ms_range_partial_kernel, dim3(RANGE_BLOCKS), dim3(256), 0, s, a.target, (long)BC * a.H * a.W, rpart);
-  hipLaunchKernelGGL(ms_range_final_kernel, dim3(1), dim3(256), 0, s, rpart, RANGE_BLOCKS, a.data_range, dr);
+  if (a.data_range <= 0.f && !a.data_range_dev)
+    hipLaunchKernelGGL(ms_range_partial_kernel, dim3(RANGE_BLOCKS), dim3(256), 0, s, a.target, (long)BC * a.H * a.W, rpart);
+  hipLaunchKernelGGL(ms_range_final_kernel, dim3(1), dim3(256), 0, s, rpart, RANGE_BLOCKS, a.data_range, a.data_range_dev, dr);
   {
     const long total = (long)NC * a.H * a.W;
     const unsigned g = (unsigned)(total / 256 / 8 > 2048 ? 2048 : (total / 256 / 8 < 1 ? 1 : total / 256 / 8));

@@ -214,6 +214,7 @@ struct MsssimArgs {
   int B, M, C, H, W;
   float alpha_w, beta_w, lam_w;
   float data_range;           // <= 0: inferred from the target on the device
+  const float* data_range_dev; // optional device float that overrides both (read when the kernels run; clamped to >= 1e-5)
   float gscale;               // dpred = gscale * d(recon)/d(pred)
   float* ws; size_t ws_floats;     // workspace of msssim_ws_floats() floats
   float* scalars;             // PU_S_RECON is ADDED to, PU_S_WMSE added to (zero them first), PU_S_MSSSIM written

@@ -307,6 +307,8 @@ class ProbabilisticUNet(nn.Module):
         self.dp_bucket_elems = 0
         self.dp_overlap_buckets = 4       # U-Net gradient buckets all-reduced under the rest of the backward (0: one all-reduce in backward())
         self._dp_works = None             # in-flight bucket collectives of the last fused elbo()
+        self.dp_global_data_range = True  # WMSE-MS-SSIM with data_range=None under data parallelism: range of the GLOBAL batch (min / max all-reduced)
+        self._range_dev = None
         self.dp_wire_dtype = None         # None: fp32 all-reduce (default); "bf16": gradients cross the wire as bfloat16 (optional compression)
         self._dp_wire = None              # persistent bf16 staging buffer of that mode
         self._comm_stream = None
@@ -831,6 +833,18 @@ class ProbabilisticUNet(nn.Module):
         if msssim:
             L.check(L.lib().pu_set_recon_wmse_msssim(self._ctx, float(alpha_w), float(beta_w), float(lam_w),
                                                      -1.0 if data_range is None else float(data_range)), self._ctx, "pu_set_recon_wmse_msssim")
+            rng_dev = None
+            if data_range is None and self._dp_active and self.dp_global_data_range:
+                # the reference infers max(target) - min(target) over the batch it sees (prob_unet_utils.py:288-289); under data
+                # parallelism that batch is the GLOBAL one: exchange the shard minima / maxima (two scalar all-reduces, on the device,
+                # no host round trip) and hand the range to the loss kernels through a device float
+                import torch.distributed as dist
+                mn, mx = torch.aminmax(target)
+                dist.all_reduce(mn, op=dist.ReduceOp.MIN, group=self._dp_group)
+                dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=self._dp_group)
+                rng_dev = (mx - mn).reshape(1).float().contiguous()
+            self._range_dev = rng_dev                                  # kept alive until the next call replaces it
+            L.check(L.lib().pu_set_recon_range_dev(self._ctx, L.ptr(rng_dev) if rng_dev is not None else None), self._ctx, "pu_set_recon_range_dev")
         for k in ("unet", "prior", "posterior"):          # the fused call overwrites every saved activation (and, with backward, the gradients)
             self._gen[k] += 1
         self._touch_xin(x)

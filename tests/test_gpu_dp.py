@@ -145,3 +145,58 @@ def test_bench_single_rank_rccl_path():
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["config"]["backend"] == "nccl" and out["config"]["world_size_seen_by_backend"] == 1
     assert out["config"]["dp_gradient_buckets"] >= 2 and out["config"]["loss_finite"] is True and out["value"] > 0
+
+
+def _worker_wmse(rank, world, initfile, outdir):
+    sys.path.insert(0, ROOT)
+    import probunet_amd as pa
+    from tests.filler import make_fields, make_eps
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method=f"file://{initfile}", rank=rank, world_size=world)
+    torch.manual_seed(3)
+    m = pa.ProbabilisticUNet(2, 1, 4, [8, 16], 8, [1, 2], 1.0, 0.5, 0.0, dtype="f32", recon="wmse_msssim").to(dev).train()
+    m.dropout = 0.0
+    m.enable_data_parallel()
+    x, y = make_fields(4, 2, 1, 128, 128, seed=43); eps = make_eps(1, 4, 4)
+    y = y.clone(); y[2:] *= 3.0                                    # the two shards see different value ranges
+    xs, ys = pa.dp.shard_batch(x, rank, world).contiguous().to(dev), pa.dp.shard_batch(y, rank, world).contiguous().to(dev)
+    es = eps[:, rank * 2:(rank + 1) * 2].contiguous().to(dev)
+    out = m.elbo(xs, ys, None, M=1, eps=es)
+    out[0].backward()
+    g = torch.cat([p.grad.flatten() for p in m.parameters()]).cpu()
+    p0 = torch.cat([p.detach().flatten() for p in m.parameters()]).cpu()
+    # the same step with the shard-local range (what rank-local inference would give): must differ, or the test proves nothing
+    m.dp_global_data_range = False
+    for p in m.parameters():
+        p.grad = None
+    m.elbo(xs, ys, None, M=1, eps=es)[0].backward()
+    g_local = torch.cat([p.grad.flatten() for p in m.parameters()]).cpu()
+    torch.save(dict(g=g, g_local=g_local), os.path.join(outdir, f"w{rank}.pt"))
+    dist.barrier()
+    if rank == 0:
+        ref = pa.ProbabilisticUNet(2, 1, 4, [8, 16], 8, [1, 2], 1.0, 0.5, 0.0, dtype="f32", init=False, recon="wmse_msssim").to(dev).train()
+        ref.dropout = 0.0
+        with torch.no_grad():
+            off = 0
+            for p in ref.parameters():
+                p.copy_(p0[off:off + p.numel()].view(p.shape).to(dev)); off += p.numel()
+        ref.elbo(x.to(dev), y.to(dev), None, M=1, eps=eps.to(dev))[0].backward()
+        torch.save(dict(g=torch.cat([p.grad.flatten() for p in ref.parameters()]).cpu()), os.path.join(outdir, "wref.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_wmse_msssim_uses_the_global_batch_range():
+    """WMSE-MS-SSIM with data_range=None infers max(target) - min(target) over the batch (prob_unet_utils.py:288-289).  Under data
+    parallelism the ranks exchange their minima / maxima, so the averaged gradient equals the single-process gradient of the global batch;
+    with rank-local ranges (dp_global_data_range = False) it does not."""
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker_wmse, args=(2, os.path.join(d, "init"), d), nprocs=2, join=True)
+        w0, w1, ref = torch.load(os.path.join(d, "w0.pt")), torch.load(os.path.join(d, "w1.pt")), torch.load(os.path.join(d, "wref.pt"))
+    assert torch.equal(w0["g"], w1["g"])
+    scale = float(ref["g"].abs().max())
+    err = float((w0["g"] - ref["g"]).abs().max())
+    err_local = float((w0["g_local"] - ref["g"]).abs().max())
+    assert err <= 5e-4 * scale + 1e-7, (err, scale)
+    assert err_local > 10 * max(err, 1e-7 * scale), (err_local, err, scale)
