@@ -330,15 +330,19 @@ def main():
     # every rank runs the same two extra steps (they contain the gradient all-reduce); only rank 0 records events
     lib.pu_set_overlap(model._ctx, 0)                # serial kernels: durations not inflated by co-running side-stream kernels
     step(); torch.cuda.synchronize()
+    NPROF = 3                                        # profiled steps: per-step figures are their mean (one step alone showed 15 % outliers)
     if rank == 0:
         lib.pu_profile_enable(1)
-    step(); torch.cuda.synchronize()
+    for _ in range(NPROF):
+        step()
+    torch.cuda.synchronize()
     lib.pu_profile_enable(0)
     lib.pu_set_overlap(model._ctx, 1)
     if rank == 0:
         ents = (L.PuProfEntry * 64)()
         n = lib.pu_profile_collect(ents, 64)
-        rows = [dict(name=ents[i].name.decode(), launches=ents[i].launches, ms=ents[i].ms, flops=ents[i].flops, bytes=ents[i].bytes) for i in range(n)]
+        rows = [dict(name=ents[i].name.decode(), launches=ents[i].launches // NPROF, ms=ents[i].ms / NPROF, flops=ents[i].flops / NPROF,
+                     bytes=ents[i].bytes / NPROF) for i in range(n)]
         rows.sort(key=lambda r: -r["ms"])
         if rows:
             # dominant kernel = the __global__ function with the largest total time in the step; for a templated kernel the roofline is
@@ -355,7 +359,7 @@ def main():
                             frac=round(achieved / peak, 4), traffic=pmc_traffic(d["name"]),
                             traffic_source="profiles/r2_pmc_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this "
                                            "command, committed; not collected in this run)",
-                            timing_source="HIP events on the kernel's launch stream, this run, side streams off",
+                            timing_source=f"HIP events on the kernel's launch stream, this run, side streams off, mean of {NPROF} steps",
                             kernel_function_ms_per_step={k: round(v, 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1])},
                             launches_per_step=d["launches"],
                             avg_launch_us=round(1e3 * d["ms"] / d["launches"], 2),

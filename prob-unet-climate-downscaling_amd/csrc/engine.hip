@@ -743,11 +743,14 @@ static int gauss_backward(pu_ctx* c, GaussNet& g, hipStream_t s) {
                           G(c, g.wmu), G(c, g.bmu), G(c, g.wls), G(c, g.bls), c->inv_scale, s, inv_dev));
   for (int i = (int)g.convs.size() - 1; i >= 0; --i) {
     TV dy = with_b(g.outs[i].g, B);
-    CKH(launch_relu_bwd<T>(with_b(g.outs[i].v, B), dy, s));
+    // ReLU backward of this layer's output: folded into the max-pool backward that produced dy when a pool follows the layer
+    // (networks: conv -> ReLU -> pool; the routed gradient is dropped where the window maximum is not positive), else its own pass
+    const bool masked_by_pool = i + 1 < (int)g.convs.size() && g.pool_before[i + 1];
+    if (!masked_by_pool) CKH(launch_relu_bwd<T>(with_b(g.outs[i].v, B), dy, s));
     if ((r = conv_wgrad<T>(c, g.convs[i], g.outs[i].g, g.ins[i].v, B, s, G(c, g.convs[i].b_off), nullptr, inv_dev))) return r;
     if (i == 0) break;
     if ((r = conv_dgrad<T>(c, g.convs[i], g.outs[i].g, g.ins[i].g, B, 0, s))) return r;
-    if (g.pool_before[i]) CKH(launch_maxpool_bwd<T>(with_b(g.outs[i - 1].v, B), with_b(g.ins[i].g, B), with_b(g.outs[i - 1].g, B), s));
+    if (g.pool_before[i]) CKH(launch_maxpool_bwd<T>(with_b(g.outs[i - 1].v, B), with_b(g.ins[i].g, B), with_b(g.outs[i - 1].g, B), s, true));
     // else ins[i] aliases outs[i-1] (same Act): gradient already in place
   }
   return PU_OK;

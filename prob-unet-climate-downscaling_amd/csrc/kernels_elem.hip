@@ -985,8 +985,9 @@ hipError_t launch_add(TV src, TV dst, int accumulate, hipStream_t s) {
 }
 
 template <typename T, bool BWD>
-__global__ void maxpool_kernel(TV x, TV y, TV dy, TV dx) {
-  // forward: y = maxpool2(x).  backward: dx = route(dy) to the first maximum of each window (aten tie rule)
+__global__ void maxpool_kernel(TV x, TV y, TV dy, TV dx, int relu_x) {
+  // forward: y = maxpool2(x).  backward: dx = route(dy) to the first maximum of each window (aten tie rule); relu_x: x is the output of a
+  // ReLU whose backward follows - the routed gradient is dropped where that maximum is not positive (= relu_bwd o maxpool_bwd in one pass)
   constexpr int VEC = ET<T>::VEC;
   const int CV = y.C / VEC;
   const long total = (long)y.B * y.H * y.W * CV;
@@ -1014,8 +1015,9 @@ __global__ void maxpool_kernel(TV x, TV y, TV dy, TV dx) {
         int arg = 0; float m = v[0][e];
 #pragma unroll
         for (int q = 1; q < 4; ++q) if (v[q][e] > m) { m = v[q][e]; arg = q; }
+        const float ge = (relu_x && !(m > 0.f)) ? 0.f : g[e];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) o[q][e] = (q == arg) ? g[e] : 0.f;
+        for (int q = 0; q < 4; ++q) o[q][e] = (q == arg) ? ge : 0.f;
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q)
@@ -1026,14 +1028,14 @@ __global__ void maxpool_kernel(TV x, TV y, TV dy, TV dx) {
 template <typename T>
 hipError_t launch_maxpool(TV x, TV y, hipStream_t s) {
   const long total = (long)y.B * y.H * y.W * (y.C / ET<T>::VEC);
-  hipLaunchKernelGGL((maxpool_kernel<T, false>), dim3(ew_grid(total)), dim3(256), 0, s, x, y, y, x);
+  hipLaunchKernelGGL((maxpool_kernel<T, false>), dim3(ew_grid(total)), dim3(256), 0, s, x, y, y, x, 0);
   return hipGetLastError();
 }
 template <typename T>
-hipError_t launch_maxpool_bwd(TV x, TV dy, TV dx, hipStream_t s) {
+hipError_t launch_maxpool_bwd(TV x, TV dy, TV dx, hipStream_t s, bool relu_x) {
   TV y = dy;
   const long total = (long)y.B * y.H * y.W * (y.C / ET<T>::VEC);
-  hipLaunchKernelGGL((maxpool_kernel<T, true>), dim3(ew_grid(total)), dim3(256), 0, s, x, y, dy, dx);
+  hipLaunchKernelGGL((maxpool_kernel<T, true>), dim3(ew_grid(total)), dim3(256), 0, s, x, y, dy, dx, relu_x ? 1 : 0);
   return hipGetLastError();
 }
 
@@ -1479,7 +1481,7 @@ hipError_t launch_nonfinite_flag(const float* g, long n, float* flag, hipStream_
   template hipError_t launch_resample_bwd<T>(TV, TV, int, int, hipStream_t);                                         \
   template hipError_t launch_add<T>(TV, TV, int, hipStream_t);                                                       \
   template hipError_t launch_maxpool<T>(TV, TV, hipStream_t);                                                        \
-  template hipError_t launch_maxpool_bwd<T>(TV, TV, TV, hipStream_t);                                                \
+  template hipError_t launch_maxpool_bwd<T>(TV, TV, TV, hipStream_t, bool);                                          \
   template hipError_t launch_relu_bwd<T>(TV, TV, hipStream_t);                                                       \
   template hipError_t launch_bias_grad<T>(TV, float*, float*, float*, int, float, hipStream_t);                             \
   template hipError_t launch_heads_fwd<T>(TV, const float*, const float*, const float*, const float*, int, float*,   \

@@ -121,7 +121,7 @@ template <typename T> hipError_t launch_resample(TV x, TV y, int mode, hipStream
 template <typename T> hipError_t launch_resample_bwd(TV dy, TV dx, int mode, int accumulate, hipStream_t); // adjoint
 template <typename T> hipError_t launch_add(TV src, TV dst, int accumulate, hipStream_t);                  // dst (+)= src
 template <typename T> hipError_t launch_maxpool(TV x, TV y, hipStream_t);
-template <typename T> hipError_t launch_maxpool_bwd(TV x, TV dy, TV dx, hipStream_t);                      // dx written
+template <typename T> hipError_t launch_maxpool_bwd(TV x, TV dy, TV dx, hipStream_t, bool relu_x = false); // dx written; relu_x: x is a ReLU output, its backward is folded in
 template <typename T> hipError_t launch_relu_bwd(TV y, TV dy, hipStream_t);                                // dy *= (y>0), in place
 // dbias[c] += sum over pixels of dy[..., c]; part: fp32 [nchunk][C]
 template <typename T> hipError_t launch_bias_grad(TV dy, float* dbias0, float* dbias1_or_null, float* part, int nchunk, float inv_scale, hipStream_t);
