@@ -650,11 +650,11 @@ hipError_t launch_fcomb_bwd(const FcombBwdArgs& a, hipStream_t s) {
   }
   if (f.F == 32 && sizeof(T) == 2) {
     if constexpr (sizeof(T) == 2) {
-      static bool attr16 = false;
-      if (!attr16) {
+      static AttrOnce attr16_once;                      // hipFuncSetAttribute is per device
+      if (!attr16_once.cur()) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(fcomb_bwd16_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 128 * 32 * 2 + 2 * 256 * 32 * 4);
         if (e != hipSuccess) return e;
-        attr16 = true;
+        attr16_once.cur() = true;
       }
       dim3 grid16((unsigned)min((long)24, (HW + 127) / 128), f.B);
       hipLaunchKernelGGL((fcomb_bwd16_kernel<T>), grid16, dim3(256), 6 * 128 * 32 * 2 + (size_t)2 * f.M * 32 * 4, s, a, zb, dzb);
