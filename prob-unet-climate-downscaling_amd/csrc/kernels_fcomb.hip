@@ -596,14 +596,15 @@ __global__ void fcomb_bwd_z_kernel(const float* __restrict__ dzb, const float* _
 }
 
 // scratch: zb and dzb live in a small workspace the engine provides through the stream-ordered pointers below.
-static float* g_fc_ws = nullptr; static long g_fc_ws_n = 0;
+static float* g_fc_ws[32] = {}; static long g_fc_ws_n[32] = {};          // one workspace per device (the current one)
 static hipError_t fc_ws(long n, float** out) {
-  if (n > g_fc_ws_n) {
-    if (g_fc_ws) { hipError_t e0 = hipFree(g_fc_ws); if (e0 != hipSuccess) return e0; }
-    hipError_t e = hipMalloc(&g_fc_ws, n * sizeof(float)); if (e != hipSuccess) return e;
-    g_fc_ws_n = n;
+  int d = 0; (void)hipGetDevice(&d); d &= 31;
+  if (n > g_fc_ws_n[d]) {
+    if (g_fc_ws[d]) { hipError_t e0 = hipFree(g_fc_ws[d]); if (e0 != hipSuccess) return e0; g_fc_ws[d] = nullptr; g_fc_ws_n[d] = 0; }
+    hipError_t e = hipMalloc(&g_fc_ws[d], n * sizeof(float)); if (e != hipSuccess) return e;
+    g_fc_ws_n[d] = n;
   }
-  *out = g_fc_ws; return hipSuccess;
+  *out = g_fc_ws[d]; return hipSuccess;
 }
 
 template <typename T>
