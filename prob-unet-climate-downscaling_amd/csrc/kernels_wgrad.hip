@@ -242,70 +242,6 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad16_kernel(WgradArgs a) {
   }
 }
 
-// dw[co][ci][tap] += inv_scale * sum_s slab[s][tap][co][ci]   (fixed order -> reproducible)
-// The slab index space [tap][cout_pad][cin_pad] is walked in float4 units (cin_pad is a multiple of 32): a block = 64 consecutive
-// units x 4 split lanes, every slab read is a coalesced 16-byte load with four of them in flight per thread, LDS combine of the
-// four lanes in a fixed order.  (The 4-byte version of this kernel took 20.5 us per launch on average, a quarter of the main kernel.)
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int split, int taps, int cout_pad, int cin_pad, int Cout, int Cin,
-                                                            float* __restrict__ dw, float inv_scale, float* db0, float* db1,
-                                                            const float* __restrict__ inv_dev) {
-  __shared__ f32x4 red[4][64];
-  if (inv_dev) inv_scale *= inv_dev[0];            // device-chosen scale of this sub-graph (latent encoders, f16)
-  const long per_tap = (long)cout_pad * cin_pad;
-  const long total4 = (long)taps * per_tap / 4;
-  const long nwb = (total4 + 63) / 64;
-  const size_t stride = (size_t)taps * per_tap;
-  if (blockIdx.x >= nwb) {                       // bias rows: slab tail [split][cout_pad]
-    __shared__ float bred[4][64];
-    const int co = (int)(blockIdx.x - nwb) * 64 + (threadIdx.x & 63);
-    const int lane = threadIdx.x >> 6;
-    const float* bs = slab + (size_t)split * stride;
-    float s = 0.f;
-    if (co < Cout) for (int k = lane; k < split; k += 4) s += bs[(size_t)k * cout_pad + co];
-    bred[lane][threadIdx.x & 63] = s;
-    __syncthreads();
-    if (lane == 0 && co < Cout) {
-      const float v = ((bred[0][threadIdx.x] + bred[1][threadIdx.x]) + (bred[2][threadIdx.x] + bred[3][threadIdx.x])) * inv_scale;
-      db0[co] += v;
-      if (db1) db1[co] += v;
-    }
-    return;
-  }
-  const long j = (long)blockIdx.x * 64 + (threadIdx.x & 63);
-  const int lane = threadIdx.x >> 6;
-  f32x4 s = {0.f, 0.f, 0.f, 0.f};
-  int ci = 0, co = 0, t = 0;
-  bool live = false;
-  if (j < total4) {
-    const long e = j * 4;
-    ci = (int)(e % cin_pad);
-    const long q = e / cin_pad;
-    co = (int)(q % cout_pad); t = (int)(q / cout_pad);
-    live = co < Cout && ci < Cin;
-    if (live) {
-      const float* p = slab + e;
-      f32x4 s0 = s, s1 = s, s2 = s, s3 = s;
-      int k = lane;
-      for (; k + 12 < split; k += 16) {
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(p + (size_t)k * stride), v1 = *reinterpret_cast<const f32x4*>(p + (size_t)(k + 4) * stride);
-        const f32x4 v2 = *reinterpret_cast<const f32x4*>(p + (size_t)(k + 8) * stride), v3 = *reinterpret_cast<const f32x4*>(p + (size_t)(k + 12) * stride);
-        s0 += v0; s1 += v1; s2 += v2; s3 += v3;
-      }
-      for (; k < split; k += 4) s0 += *reinterpret_cast<const f32x4*>(p + (size_t)k * stride);
-      s = (s0 + s1) + (s2 + s3);
-    }
-  }
-  red[lane][threadIdx.x & 63] = s;
-  __syncthreads();
-  if (lane == 0 && live) {
-    const f32x4 v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-    float* d = dw + ((size_t)co * Cin + ci) * taps + t;
-#pragma unroll
-    for (int e4 = 0; e4 < 4; ++e4)
-      if (ci + e4 < Cin) d[(size_t)e4 * taps] += v[e4] * inv_scale;
-  }
-}
-
 template <typename T, int KS, int TH, int TW, int BCI, int NW = 4, int WBCO = 64>
 static hipError_t launch_wg16(const WgradArgs& a, hipStream_t s, WgradReduce* red) {
   constexpr int PADP = KS / 2, BM = TH * TW, NPH = (TH + 2 * PADP) * (TW + 2 * PADP), TAPS = KS * KS;
@@ -341,7 +277,8 @@ static hipError_t launch_wg16(const WgradArgs& a, hipStream_t s, WgradReduce* re
   return hipGetLastError();
 }
 
-// Second form of the slab reduction (default; PU_WG_REDUCE_OLD=1 selects the kernel above).  What the profile of the first form showed:
+// dw[co][ci][tap] += inv_scale * sum_s slab[s][tap][co][ci]   (fixed order -> reproducible).  Second form of this reduction; what the
+// profile of the first one (64 units x 4 split lanes per block, one unit per tap, bias rows in 64-cout x 4-lane blocks) showed:
 //  * layers with small tiles and deep splits (32 x 32 x 9 tile, 512 slabs) ran 37 blocks whose threads each walked 128 dependent
 //    loads (31.7 us for 18.9 MB);
 //  * layers with large weight tensors (512 x 512 x 9 and up) spent their time in the 4-byte read-modify-write of dw at stride `taps`:
@@ -489,14 +426,7 @@ static void launch_reduce2_l(const WgradReduce& r, int L, hipStream_t s) {
 }
 
 hipError_t launch_wgrad16_reduce(const WgradReduce& r, hipStream_t s) {
-  static const bool old_form = getenv("PU_WG_REDUCE_OLD") != nullptr;
-  if (old_form || (r.taps != 9 && r.taps != 1)) {
-    const long total4 = (long)r.taps * r.cout_pad * r.cin_pad / 4;
-    const unsigned nbias_blocks = r.db0 ? (unsigned)cdiv(r.Cout, 64) : 0u;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total4 + 63) / 64) + nbias_blocks), dim3(256), 0, s, r.slab, r.split, r.taps,
-                       r.cout_pad, r.cin_pad, r.Cout, r.Cin, r.dw, r.inv_scale, r.db0, r.db1, r.inv_dev);
-    return hipGetLastError();
-  }
+  if (r.taps != 9 && r.taps != 1) return hipErrorInvalidValue;
   // Split lanes per unit: 4 or 16 (a lane row of a block then reads >= 256 contiguous bytes of one slab; 64 lanes x 64-byte rows measured
   // 36 us where this form takes ~10), 16 only when the split is that deep and 4 lanes would leave fewer than 1024 blocks.  All taps per
   // thread only where that still gives >= 1024 blocks (weights of 256 x 256 x 9 and up - the layers whose dw does not stay in L2).
