@@ -149,6 +149,11 @@ int pu_last_latent(pu_ctx*, int which, float* mu, float* sigma, int B, void* str
  * sample+fcomb").  Parameters are read at replay time, so weight updates are seen as long as pu_params_changed is NOT pending
  * (a pending re-pack runs eagerly before the replay).  Off by default; the captured graphs die with the ctx. */
 int pu_set_sample_graph(pu_ctx*, int on);
+/* What the hipGraph path has done since the ctx was created (no guessing from timings): graphs captured and instantiated, launches
+ * served by hipGraphLaunch (the launch that follows a capture included), and calls that ran eagerly WHILE the graph path was on
+ * (first sight of an argument tuple, a failed capture, profiling enabled).  The cache key is the full argument tuple - every pointer,
+ * B, n - so a caller that wants replays must pass the same buffers again (ProbabilisticUNet.sample(out=...)). */
+int pu_sample_graph_stats(pu_ctx*, int64_t* captures, int64_t* replays, int64_t* eager_fallbacks);
 int pu_sample(pu_ctx*, const float* x, const float* target_or_null, const float* eps, int B, int n,
               float* out, float* mu, float* sigma, void* stream);
 

@@ -96,6 +96,7 @@ def lib():
     L.pu_grad_buckets.restype = i32; L.pu_grad_buckets.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), i32, C.POINTER(i32)]
     L.pu_grad_bucket_wait.restype = i32; L.pu_grad_bucket_wait.argtypes = [vp, i32, vp]
     L.pu_set_sample_graph.restype = i32; L.pu_set_sample_graph.argtypes = [vp, i32]
+    L.pu_sample_graph_stats.restype = i32; L.pu_sample_graph_stats.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
     L.pu_drop_site_count.restype = i32; L.pu_drop_site_count.argtypes = [vp]
     L.pu_drop_site.restype = i32; L.pu_drop_site.argtypes = [vp, i32, C.c_char_p, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.pu_set_drop_masks.restype = i32; L.pu_set_drop_masks.argtypes = [vp, vp, i32, vp]

@@ -100,6 +100,8 @@ struct pu_ctx {
   // cfg5: captured launch sequences of pu_sample / pu_sample_hr
   struct SampleGraph { std::vector<const void*> key; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
   bool sample_graph_on = false; std::vector<SampleGraph> sample_graphs; std::vector<std::vector<const void*>> sample_seen;
+  long graph_captures = 0, graph_replays = 0, graph_eager = 0;      // pu_sample_graph_stats
+  size_t max_tensor_elems = 0;                                      // largest B*H*W*ld of the plan (kernels index pixels with 32-bit element offsets)
 };
 
 static std::string g_create_err;
@@ -133,6 +135,7 @@ static void* arena_alloc(pu_ctx* c, size_t bytes) {
 }
 static TV alloc_tv(pu_ctx* c, int B, int H, int W, int C) {
   TV t; t.B = B; t.H = H; t.W = W; t.C = C; t.ld = C;
+  if ((size_t)B * H * W * C > c->max_tensor_elems) c->max_tensor_elems = (size_t)B * H * W * C;
   t.p = arena_alloc(c, (size_t)B * H * W * C * c->esz);
   return t;
 }
@@ -202,7 +205,7 @@ static int build_plan(pu_ctx* c) {
   const int mb = cf.max_batch, D = cf.depth, mc = cf.model_channels;
   const size_t esz = c->esz;
   c->table.clear(); c->nparams = 0; c->packed_elems = 0; c->descs.clear(); c->flags.clear();
-  c->enc.clear(); c->dec.clear(); c->arena_used = 0; c->max_gn_c = 0; c->drop_sites.clear();
+  c->enc.clear(); c->dec.clear(); c->arena_used = 0; c->max_gn_c = 0; c->drop_sites.clear(); c->max_tensor_elems = 0;
   c->prior = GaussNet(); c->post = GaussNet();
   const int emb = mc * 4;
   add_param(c, "unet.map_label.weight", {emb, 1});
@@ -789,6 +792,13 @@ int pu_create(const pu_config* cfg, int device, pu_ctx** out) {
   c->planning = true;
   int r = build_plan(c);
   if (r != PU_OK) return bail(r);
+  if (c->max_tensor_elems >= ((size_t)1 << 32)) {
+    // the convolution kernels keep per-pixel ELEMENT offsets in 32 bits (kernels_conv.hip staging plan): a tensor of 2^32 elements or
+    // more would wrap silently
+    char b_[256]; snprintf(b_, sizeof b_, "max_batch %d x %d x %d: the largest activation has %zu elements (>= 2^32, the engine's 32-bit pixel "
+                           "offset range); lower max_batch", cfg->max_batch, cfg->H, cfg->W, c->max_tensor_elems);
+    c->err = b_; return bail(PU_ERR_INVALID);
+  }
   DeviceGuard dg(device);                                  // the caller's current device is restored on every return path
   int cur_dev = -1;
   hipError_t e = hipGetDevice(&cur_dev);
@@ -1156,14 +1166,14 @@ static int sample_impl(pu_ctx* c, const float* x, const float* target, const flo
   if (n < 1 || n > c->cfg.max_members) FAIL(PU_ERR_INVALID, "n=%d outside [1, max_members=%d]", n, c->cfg.max_members);
   hipStream_t s = (hipStream_t)stream;
   if ((r = ensure_packed(c, s))) return r;                 // eager, never inside a capture (the weights may have changed)
-  auto eager = [&]() { return sample_body(c, x, target, eps, B, n, out, mu, sigma, lrinterp, resid_std, epsilon, softplus, softplus_c, s); };
+  auto eager = [&]() { if (c->sample_graph_on) ++c->graph_eager; return sample_body(c, x, target, eps, B, n, out, mu, sigma, lrinterp, resid_std, epsilon, softplus, softplus_c, s); };
   if (!c->sample_graph_on || !c->side2 || prof_enabled()) return eager();
   // ---- hipGraph path: the first call with a given argument tuple runs eagerly (it also performs the one-time
   // hipFuncSetAttribute calls, which are illegal inside a capture), the second captures, later ones replay
   union { float f; uintptr_t u; } e0, e1; e0.u = 0; e1.u = 0; e0.f = epsilon; e1.f = softplus_c;
   std::vector<const void*> key = {x, target, eps, out, mu, sigma, lrinterp, resid_std, (const void*)(uintptr_t)B, (const void*)(uintptr_t)n,
                                   (const void*)(uintptr_t)softplus, (const void*)e0.u, (const void*)e1.u};
-  for (auto& g : c->sample_graphs) if (g.key == key) { CKH(hipGraphLaunch(g.exec, s)); c->unet_B = B; return PU_OK; }
+  for (auto& g : c->sample_graphs) if (g.key == key) { CKH(hipGraphLaunch(g.exec, s)); ++c->graph_replays; c->unet_B = B; return PU_OK; }
   bool seen = false;
   for (auto& k : c->sample_seen) if (k == key) { seen = true; break; }
   if (!seen) { if (c->sample_seen.size() >= 64) c->sample_seen.clear(); c->sample_seen.push_back(key); return eager(); }
@@ -1184,12 +1194,21 @@ static int sample_impl(pu_ctx* c, const float* x, const float* target, const flo
   }
   pu_ctx::SampleGraph sg; sg.key = key; sg.graph = graph; sg.exec = exec;
   c->sample_graphs.push_back(sg);
+  ++c->graph_captures;
   CKH(hipGraphLaunch(exec, s));
+  ++c->graph_replays;
   return PU_OK;
 }
 int pu_set_sample_graph(pu_ctx* c, int on) {
   if (!c) return PU_ERR_INVALID;
   c->sample_graph_on = on != 0;
+  return PU_OK;
+}
+int pu_sample_graph_stats(pu_ctx* c, int64_t* captures, int64_t* replays, int64_t* eager_fallbacks) {
+  if (!c) return PU_ERR_INVALID;
+  if (captures) *captures = c->graph_captures;
+  if (replays) *replays = c->graph_replays;
+  if (eager_fallbacks) *eager_fallbacks = c->graph_eager;
   return PU_OK;
 }
 int pu_drop_site_count(pu_ctx* c) { return c ? (int)c->drop_sites.size() : -1; }

@@ -878,12 +878,16 @@ class ProbabilisticUNet(nn.Module):
         return total, recon_list, klv, kl2v
 
     @torch.no_grad()
-    def sample(self, x, n: int, target=None, eps: Optional[torch.Tensor] = None, _return_dist: bool = False):
+    def sample(self, x, n: int, target=None, eps: Optional[torch.Tensor] = None, _return_dist: bool = False, out: Optional[torch.Tensor] = None):
         """n samples per input with the U-Net and the latent encoder evaluated ONCE (the pattern of
         latent_exploration.py:119-129; replaces the n x model(x, training=False) loop of
-        train_prob_unet_model.py:244-247).  Returns [B, n, Cout, H, W]."""
+        train_prob_unet_model.py:244-247).  Returns [B, n, Cout, H, W].
+        out: optional preallocated fp32 result buffer of that shape.  With `use_sample_graph` the captured hipGraph is keyed on
+        every pointer of the call, so a sampling loop that wants replays passes the same x / eps / out buffers each time
+        (`sample_graph_stats()` reports what actually happened)."""
         x = self._prep(x)
         B, Cc, H, W = x.shape
+        out_given = out is not None
         self._ensure(H, W, B, n)
         self._params_dirty(force=False)
         if target is not None:
@@ -893,8 +897,8 @@ class ProbabilisticUNet(nn.Module):
         if eps is None:
             eps = torch.randn(n, B, self.latent_dim, device=x.device, dtype=torch.float32)
         eps = eps.contiguous().float()
-        out = torch.empty(B, n, self.num_classes, H, W, device=x.device, dtype=torch.float32)
-        mu = torch.empty(B, self.latent_dim, device=x.device, dtype=torch.float32); sg = torch.empty_like(mu)
+        out = self._out_buffer(out, (B, n, self.num_classes, H, W), x.device)
+        mu, sg = self._latent_out_buffers(B, x.device, stable=out_given)
         self._gen["unet"] += 1; self._gen["posterior" if target is not None else "prior"] += 1; self._touch_xin(x)
         L.check(L.lib().pu_sample(self._ctx, L.ptr(x), L.ptr(target), L.ptr(eps), B, n, L.ptr(out), L.ptr(mu), L.ptr(sg), self._stream()),
                 self._ctx, "pu_sample")
@@ -904,7 +908,7 @@ class ProbabilisticUNet(nn.Module):
 
     @torch.no_grad()
     def sample_hr(self, x, n: int, lrinterp, residual_std, epsilon: float = 1e-10, softplus: bool = False, softplus_c: float = 1e-7,
-                  target=None, eps: Optional[torch.Tensor] = None):
+                  target=None, eps: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
         """`sample()` with ClimExDataset.residual_to_hr (climex_utils.py:277-285) fused into the Fcomb store: returns
         physical-unit fields hr[b, s] = lrinterp[b] + residual[b, s] * (residual_std + epsilon), [B, n, Cout, H, W], without the
         per-sample `.cpu()` round trip of train_prob_unet_model.py:246.  softplus=True additionally applies
@@ -929,12 +933,41 @@ class ProbabilisticUNet(nn.Module):
         if eps is None:
             eps = torch.randn(n, B, self.latent_dim, device=x.device, dtype=torch.float32)
         eps = eps.contiguous().float()
-        out = torch.empty(B, n, self.num_classes, H, W, device=x.device, dtype=torch.float32)
+        out = self._out_buffer(out, (B, n, self.num_classes, H, W), x.device)
         self._gen["unet"] += 1; self._gen["posterior" if target is not None else "prior"] += 1; self._touch_xin(x)
         L.check(L.lib().pu_sample_hr(self._ctx, L.ptr(x), L.ptr(target), L.ptr(eps), B, n, L.ptr(lrinterp), L.ptr(residual_std),
                                      float(epsilon), 1 if softplus else 0, float(softplus_c), L.ptr(out), None, None, self._stream()),
                 self._ctx, "pu_sample_hr")
         return out
+
+    @staticmethod
+    def _out_buffer(out, shape, device):
+        if out is None:
+            return torch.empty(*shape, device=device, dtype=torch.float32)
+        if tuple(out.shape) != tuple(shape) or out.dtype != torch.float32 or out.device != device or not out.is_contiguous():
+            raise ValueError(f"out must be a contiguous fp32 tensor of shape {tuple(shape)} on {device}")
+        return out
+
+    def _latent_out_buffers(self, B, device, stable):
+        """(mu, sigma) result buffers of sample(); with a caller-provided `out` they are kept per batch size so that every pointer of
+        the call repeats (the hipGraph cache key)."""
+        if not stable:
+            mu = torch.empty(B, self.latent_dim, device=device, dtype=torch.float32)
+            return mu, torch.empty_like(mu)
+        cache = self.__dict__.setdefault("_mu_sg_cache", {})
+        k = (B, str(device))
+        if k not in cache:
+            mu = torch.empty(B, self.latent_dim, device=device, dtype=torch.float32)
+            cache[k] = (mu, torch.empty_like(mu))
+        return cache[k]
+
+    def sample_graph_stats(self):
+        """(captures, replays, eager_fallbacks) of the hipGraph sampling path since the engine context was created."""
+        if self._ctx is None:
+            return (0, 0, 0)
+        a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        L.check(L.lib().pu_sample_graph_stats(self._ctx, C.byref(a), C.byref(b), C.byref(c)), self._ctx, "pu_sample_graph_stats")
+        return (int(a.value), int(b.value), int(c.value))
 
     @staticmethod
     def reconstruct(residual, lrinterp, residual_std, epsilon: float = 1e-10):

@@ -130,6 +130,19 @@ def test_cfg5_64_prior_samples_at_256(dtype):
         m.assume_static_parameters = True
         out2 = m.sample(x, n, eps=eps); out3 = m.sample(x, n, eps=eps)
         assert torch.equal(out2, out) and torch.equal(out3, out)
+        # hipGraph path observed, not assumed (pu_sample_graph_stats): with caller-stable buffers (x, eps, out=) the first call of a
+        # tuple is eager, the second captures + launches, every later one replays; results stay bit-identical to the eager call
+        m.use_sample_graph = True
+        from probunet_amd import _lib as L_
+        L_.lib().pu_set_sample_graph(m._ctx, 1)
+        c0, r0, e0 = m.sample_graph_stats()
+        buf = torch.empty_like(out)
+        for it in range(4):
+            m.sample(x, n, eps=eps, out=buf)
+            assert torch.equal(buf, out), it
+        c1, r1, e1 = m.sample_graph_stats()
+        assert (c1 - c0, r1 - r0, e1 - e0) == (1, 3, 1), (c0, r0, e0, c1, r1, e1)
+        L_.lib().pu_set_sample_graph(m._ctx, 0); m.use_sample_graph = False
         # the 64-sample latent_exploration call on ONE feature map broadcast with expand() (stride 0)
         z64 = mu[:1] + sg[:1] * eps[:, 0]
         g64 = m.fcomb(feat[:1].expand(n, -1, -1, -1), z64)
@@ -186,3 +199,15 @@ def test_cfg3_batch32_shard_mean_and_determinism():
     gm = 0.5 * (ga.double() + gb.double())
     rel = float((gf.double() - gm).norm() / gm.norm())
     assert rel < 2e-2, rel                                                 # f16 activations; identical in exact arithmetic
+
+
+def test_create_rejects_plans_beyond_the_32_bit_pixel_offset_range():
+    """pu_create fails loudly (PU_ERR_INVALID, host-side, before any allocation) when the largest activation of the plan reaches 2^32
+    elements: the convolution staging plans keep per-pixel element offsets in 32 bits (B > 682 at cfg3: 683 x 256 x 256 x 96)."""
+    import ctypes as C
+    from probunet_amd import _lib as L_
+    m = pa.ProbabilisticUNet(4, 1, 12, NF3, 32, MULT3, 1.0, 1.0, 0.0, dtype="f16", init=False)
+    ctx = C.c_void_p()
+    cfg = m._cfg_struct(256, 256, 683, 1)
+    rc = L_.lib().pu_create(C.byref(cfg), 0, C.byref(ctx))
+    assert rc == -1 and b"2^32" in L_.lib().pu_last_error(None)
