@@ -220,6 +220,53 @@ def bench_sample(args, steps=None, warmup=None, inputs=None, graph=True):
                                              eager_in_timed_region=g1[2] - g0[2], source="pu_sample_graph_stats")))
 
 
+def dp_diagnostics(args, model, step, barrier, dist, world, rank, device, ms_per_step, elapsed_local):
+    """What makes the first multi-GPU run diagnosable, measured AFTER the timed region (never part of `value`):
+    per-rank step time of the timed region; the step time with the gradient all-reduce issued in buckets under the backward
+    (--dp-buckets, the default path), as ONE collective after the backward (buckets = 0), and with no collective at all; the
+    differences are the communication time left exposed by each scheme."""
+    from probunet_amd import _lib as L
+    K = max(3, min(args.steps, 6))
+    per_rank = torch.zeros(world, device=device, dtype=torch.float64)
+    per_rank[rank] = 1e3 * elapsed_local / args.steps
+    if world > 1:
+        dist.all_reduce(per_rank, op=dist.ReduceOp.SUM)
+
+    def timed():
+        step(); barrier()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            step()
+        barrier()
+        t = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return 1e3 * float(t.item()) / K
+
+    def set_buckets(n):
+        model.dp_overlap_buckets = n
+        L.lib().pu_set_grad_buckets(model._ctx, int(n))
+
+    res = {}
+    set_buckets(args.dp_buckets); res["ms_per_step_buckets_%d" % args.dp_buckets] = round(timed(), 3)
+    if args.dp_buckets != 0:
+        set_buckets(0); res["ms_per_step_buckets_0"] = round(timed(), 3)
+    was = model._dp_active
+    model._dp_active = False; set_buckets(0)                  # no gradient exchange at all (parameters drift apart: diagnostics only)
+    res["ms_per_step_no_allreduce"] = round(timed(), 3)
+    model._dp_active = was; set_buckets(args.dp_buckets)
+    base = res["ms_per_step_no_allreduce"]
+    res["exposed_comm_ms_buckets_%d" % args.dp_buckets] = round(res["ms_per_step_buckets_%d" % args.dp_buckets] - base, 3)
+    if "ms_per_step_buckets_0" in res:
+        res["exposed_comm_ms_buckets_0"] = round(res["ms_per_step_buckets_0"] - base, 3)
+    res["per_rank_ms_per_step"] = [round(float(v), 3) for v in per_rank.tolist()]
+    res["steps_per_variant"] = K
+    res["gradient_bytes_per_rank"] = int(model._nparams) * (2 if args.dp_wire == "bf16" else 4)
+    res["note"] = ("measured after the timed region; exposed = step time minus the no-all-reduce step time (max over ranks); the collective is "
+                   "torch.distributed's all_reduce on backend %s" % (dist.get_backend(),))
+    return res
+
+
 def self_launch(n):
     """python bench.py --gpus N with no launcher around it: become the parent of `torch.distributed.run` with one rank per GPU.
     Nothing in this process has touched the GPU yet (importing torch does not), and the children are fresh processes - never an
@@ -336,6 +383,7 @@ def main():
         loss = step()
     barrier()
     elapsed = time.perf_counter() - t0
+    elapsed_local = elapsed
     el = torch.tensor([elapsed], device=device, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
@@ -420,6 +468,8 @@ def main():
             out["secondary"] = dict(error=f"{type(e).__name__}: {e}")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(cfg)
+    if world > 1 or force_dist:
+        out["dp_diagnostics"] = dp_diagnostics(args, model, step, barrier, dist, world, rank, device, ms_per_step, elapsed_local)
     if rank == 0:
         print(json.dumps(out, allow_nan=False), flush=True)
     if world > 1 or force_dist:

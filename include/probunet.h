@@ -133,6 +133,10 @@ int pu_elbo_fwd_bwd(pu_ctx*, const float* x, const float* target, const float* e
 int pu_set_grad_buckets(pu_ctx*, int n_unet_buckets);
 int pu_grad_buckets(pu_ctx*, int64_t* lo, int64_t* hi, int max, int* n);
 int pu_grad_bucket_wait(pu_ctx*, int k, void* stream);
+/* g[0..n) *= host_factor * (scale_dev ? *scale_dev : 1), as ONE conditional pass: when the factor is exactly 1 (the grad_output of
+ * loss.backward(), a device scalar the host does not know) the kernel returns after one load per thread and the buffer is not touched.
+ * Lets the Python shim hand the engine's gradient buffer to p.grad without a scaled copy.  g must be 16-byte aligned. */
+int pu_scale_grads(float* g, int64_t n, const float* scale_dev_or_null, float host_factor, void* stream);
 /* flag[0] = 1.0f if any of the n floats is inf / NaN, else unchanged (zero it first); ~60 us for the 76 M gradients of cfg3. */
 int pu_nonfinite_flag(const float* g, int64_t n, float* flag, void* stream);
 

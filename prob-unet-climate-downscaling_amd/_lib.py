@@ -91,6 +91,7 @@ def lib():
     L.pu_adamw_step_dev.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, vp, vp]
     L.pu_adamw_prepare.restype = i32; L.pu_adamw_prepare.argtypes = [vp, vp, f32, f32, f32, vp]
     L.pu_adamw_apply.restype = i32; L.pu_adamw_apply.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, vp, vp]
+    L.pu_scale_grads.restype = i32; L.pu_scale_grads.argtypes = [vp, i64, vp, f32, vp]
     L.pu_nonfinite_flag.restype = i32; L.pu_nonfinite_flag.argtypes = [vp, i64, vp, vp]
     L.pu_set_grad_buckets.restype = i32; L.pu_set_grad_buckets.argtypes = [vp, i32]
     L.pu_grad_buckets.restype = i32; L.pu_grad_buckets.argtypes = [vp, C.POINTER(i64), C.POINTER(i64), i32, C.POINTER(i32)]

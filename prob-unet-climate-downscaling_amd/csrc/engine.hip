@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <deque>
 #include <string>
 #include <vector>
@@ -35,6 +36,8 @@ struct GNL {
   float* stat = nullptr; float* coef = nullptr;
   uint32_t drop_stream = 0; bool dropout = false; int resample = RS_NONE;
   int drop_site = -1;                  // index into pu_ctx::drop_sites when this GroupNorm is followed by dropout
+  bool fuse_bwd = false;               // pass 1 of the backward rides in the epilogue of the data gradient that produces dy (GNBwdFuse)
+  uint8_t* keep_bits = nullptr;        // dropout keep decisions saved by the forward apply, read by the backward (16-bit engines)
 };
 struct Act { TV v; TV g; int flag = -1; };          // value view, gradient view, index of the shared "grad written" flag
 
@@ -78,6 +81,8 @@ struct pu_ctx {
   // scratch
   float* wg_slab = nullptr; long wg_slab_floats = 0;
   float* gn_part = nullptr; float* gn_part2 = nullptr; float* gn_coef2 = nullptr; float* bias_part = nullptr; TV dv_scratch;
+  float* gn_rows = nullptr; size_t gn_rows_per_img = 0; int gn_rows_cap = 0;   // pass-1 rows written by data-gradient epilogues: [B][slots][C][2]
+  long fuse_bwd_minhw = 128L * 128;     // GroupNorm sites with at least this many pixels use the fused backward (PU_GN_FUSE_BWD_MINHW; 0 = off)
   float *z = nullptr, *dz = nullptr, *preds = nullptr, *dpreds = nullptr, *kl = nullptr, *kl2 = nullptr, *scal = nullptr;
   Act fc_feat;                      // standalone fcomb input (converted) + its gradient
   float* fc_z = nullptr; int fc_B = 0; int fc_bcast = 0;
@@ -101,6 +106,9 @@ struct pu_ctx {
   struct SampleGraph { std::vector<const void*> key; hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; };
   bool sample_graph_on = false; std::vector<SampleGraph> sample_graphs; std::vector<std::vector<const void*>> sample_seen;
   long graph_captures = 0, graph_replays = 0, graph_eager = 0;      // pu_sample_graph_stats
+  // fused ELBO backward, 16-bit engines: convolution weights / biases are WRITTEN by their (single) weight-gradient reduction, so only the
+  // accumulated parameters (GroupNorm, Fcomb, heads, dead parameters) are zeroed beforehand: `zero_ranges` = complement of the conv ranges
+  std::vector<std::pair<int64_t, int64_t>> conv_ranges; long* zero_ranges_dev = nullptr; int n_zero_ranges = 0; bool grad_overwrite = false;
   size_t max_tensor_elems = 0;                                      // largest B*H*W*ld of the plan (kernels index pixels with 32-bit element offsets)
 };
 
@@ -170,6 +178,8 @@ static int64_t add_param(pu_ctx* c, const std::string& name, std::initializer_li
 
 static void setup_conv(pu_ctx* c, ConvL& L, int cin, int cout, int ks, int64_t w_off, int64_t b_off, bool need_dgrad, int rh, int rw) {
   L.cin = cin; L.cout = cout; L.ks = ks; L.w_off = w_off; L.b_off = b_off; L.need_dgrad = need_dgrad;
+  c->conv_ranges.push_back({w_off, w_off + (int64_t)cout * cin * ks * ks});
+  if (b_off >= 0) c->conv_ranges.push_back({b_off, b_off + cout});
   L.frag = conv_uses_frag_layout((int)c->esz, rh, rw);
   const int taps = ks * ks;
   L.cin_pk = rup(cin, 32); L.rows_fwd = rup(cout, 32);
@@ -195,6 +205,12 @@ static void setup_gn(pu_ctx* c, GNL& n, int C, long HW, int64_t g_off, int64_t b
   n.stat = alloc_f32(c, (size_t)mb * n.G * 2);
   n.coef = alloc_f32(c, (size_t)mb * C * 4);
   if (C > c->max_gn_c) c->max_gn_c = C;
+  if (dropout && c->esz == 2 && resample == RS_NONE && !getenv("PU_NO_KEEP_BITS")) n.keep_bits = (uint8_t*)arena_alloc(c, (size_t)mb * HW * C / 8);
+  n.fuse_bwd = c->esz == 2 && resample == RS_NONE && c->fuse_bwd_minhw > 0 && HW >= c->fuse_bwd_minhw && HW > 1024;
+  if (n.fuse_bwd) {
+    const size_t per = (size_t)(HW / 64) * C * 2;          // at most one row per 64 pixels (a wave's share of a tile) and channel
+    if (per > c->gn_rows_per_img) c->gn_rows_per_img = per;
+  }
 }
 
 // ------------------------------------------------------------------ plan construction
@@ -205,7 +221,7 @@ static int build_plan(pu_ctx* c) {
   const int mb = cf.max_batch, D = cf.depth, mc = cf.model_channels;
   const size_t esz = c->esz;
   c->table.clear(); c->nparams = 0; c->packed_elems = 0; c->descs.clear(); c->flags.clear();
-  c->enc.clear(); c->dec.clear(); c->arena_used = 0; c->max_gn_c = 0; c->drop_sites.clear(); c->max_tensor_elems = 0;
+  c->enc.clear(); c->dec.clear(); c->arena_used = 0; c->max_gn_c = 0; c->drop_sites.clear(); c->max_tensor_elems = 0; c->gn_rows_per_img = 0; c->conv_ranges.clear();
   c->prior = GaussNet(); c->post = GaussNet();
   const int emb = mc * 4;
   add_param(c, "unet.map_label.weight", {emb, 1});
@@ -395,6 +411,7 @@ static int build_plan(pu_ctx* c) {
   c->gn_part = alloc_f32(c, (size_t)mb * 64 * c->max_gn_c * 2);
   c->gn_part2 = alloc_f32(c, (size_t)mb * 64 * c->max_gn_c * 2);
   c->gn_coef2 = alloc_f32(c, (size_t)mb * c->max_gn_c * 3);
+  c->gn_rows = c->gn_rows_per_img ? alloc_f32(c, (size_t)mb * c->gn_rows_per_img) : nullptr;
   c->bias_part = alloc_f32(c, (size_t)256 * 1024);
   c->wg_slab_floats = c->dt == PU_F32 ? 0 : 32L * 1024 * 1024;
   c->wg_slab = c->wg_slab_floats ? alloc_f32(c, (size_t)c->wg_slab_floats * pu_ctx::NSLAB) : nullptr;
@@ -449,9 +466,20 @@ static int conv_fwd(pu_ctx* c, const ConvL& L, TV in, TV out, int B, bool relu, 
   return PU_OK;
 }
 // dx (+)= dgrad(dy)
+struct GnbReq { const GNL* n = nullptr; TV x; int train = 0; uint64_t seed = 0; int slots = 0; };   // in: the GroupNorm whose dy this data gradient is; out: slots
 template <typename T>
-static int conv_dgrad(pu_ctx* c, const ConvL& L, TV dy, TV dx, int B, int accumulate, hipStream_t s) {
+static int conv_dgrad(pu_ctx* c, const ConvL& L, TV dy, TV dx, int B, int accumulate, hipStream_t s, GnbReq* gq = nullptr) {
   ConvArgs a; memset(&a, 0, sizeof a);
+  if (gq) gq->slots = 0;
+  if (gq && gq->n && gq->n->fuse_bwd && c->gn_rows && !accumulate && dx.H > 0) {
+    const GNL& n = *gq->n;
+    a.gnb.x = gq->x.p; a.gnb.x_ld = gq->x.ld; a.gnb.coef = n.coef; a.gnb.C = n.C;
+    a.gnb.drop.drop_p = (n.dropout && gq->train) ? c->cfg.dropout_p : 0.f; a.gnb.drop.seed = gq->seed; a.gnb.drop.stream = n.drop_stream; a.gnb.drop.b0 = 0;
+    if (a.gnb.drop.drop_p > 0.f && c->drop_masks && n.drop_site >= 0 && B == c->drop_masks_B)
+      a.gnb.drop.mask = c->drop_masks + c->drop_sites[n.drop_site].off * (size_t)c->drop_masks_B;
+    if (a.gnb.drop.drop_p > 0.f) a.gnb.drop.bits = n.keep_bits;
+    a.gnb.part = c->gn_rows; a.gnb.cap = (int)(c->gn_rows_per_img / ((size_t)n.C * 2)); a.gnb.slots = &gq->slots;
+  }
   a.in = dy.p; a.in_ld = dy.ld; a.Cin = L.cout;
   a.wpk = (char*)c->packed + (size_t)L.pk_bwd * c->esz; a.cin_pk = L.cout_pk; a.cout_pk = L.rows_bwd; a.taps = L.ks * L.ks;
   a.bias = nullptr; a.res = nullptr;
@@ -511,6 +539,7 @@ static int conv_wgrad(pu_ctx* c, const ConvL& L, TV dy, TV in, int B, hipStream_
   a.dy = dy.p; a.dy_ld = dy.ld; a.Cout = L.cout; a.in = in.p; a.in_ld = in.ld; a.Cin = L.cin;
   a.dw = G(c, L.w_off); a.B = B; a.H = dy.H; a.W = dy.W; a.taps = L.ks * L.ks;
   a.slab = c->wg_slab; a.slab_floats = c->wg_slab_floats; a.inv_scale = c->inv_scale;
+  a.overwrite = (c->grad_overwrite && sizeof(T) == 2) ? 1 : 0;
   hipStream_t ws = s;
   if constexpr (sizeof(T) == 2) {
     int r = fork_side(c, s, &ws); if (r) return r;
@@ -537,6 +566,7 @@ static GNArgs gn_args(pu_ctx* c, const GNL& n, TV x, TV y, int B, int train, uin
   a.drop_p = (n.dropout && train) ? c->cfg.dropout_p : 0.f; a.drop_seed = seed; a.drop_stream = n.drop_stream;
   if (a.drop_p > 0.f && c->drop_masks && n.drop_site >= 0 && B == c->drop_masks_B)      // injected masks: [site][B][H][W][C] uint8
     a.drop_mask = c->drop_masks + c->drop_sites[n.drop_site].off * (size_t)c->drop_masks_B;
+  if (a.drop_p > 0.f) a.keep_bits = n.keep_bits;
   a.part = c->gn_part; a.stat = n.stat; a.coef = n.coef; a.nchunk = n.nchunk;
   return a;
 }
@@ -565,8 +595,9 @@ static int gn_fwd(pu_ctx* c, const GNL& n, TV x, TV y, int B, int train, uint64_
 }
 template <typename T>
 static int gn_bwd(pu_ctx* c, const GNL& n, TV x, TV y, TV dy, TV dx, int accumulate, int B, int train, uint64_t seed, hipStream_t s,
-                  const TV* add = nullptr) {
+                  const TV* add = nullptr, int dv_slots = 0) {
   GNBwdArgs a; memset(&a, 0, sizeof a);
+  if (dv_slots > 0) { a.rows = c->gn_rows; a.nrows = dv_slots; }      // dy holds dv, pass 1 was done by the data-gradient epilogue
   if (add && n.resample == RS_NONE) a.add = with_b(*add, B);
   a.f = gn_args(c, n, x, y, B, train, seed);
   a.dy = with_b(dy, B);
@@ -654,7 +685,8 @@ static int block_bwd(pu_ctx* c, Block& b, int B, int train, uint64_t seed, bool 
   }
   // conv1
   if ((r = conv_wgrad<T>(c, b.conv1, dout, b.h1.v, B, s, G(c, b.conv1.b_off), b.skip == SK_CONV ? G(c, b.skipc.b_off) : nullptr))) return r;
-  if ((r = conv_dgrad<T>(c, b.conv1, dout, b.h1.g, B, 0, s))) return r;
+  GnbReq q1; q1.n = &b.n1; q1.x = b.c0.v; q1.train = train; q1.seed = seed;
+  if ((r = conv_dgrad<T>(c, b.conv1, dout, b.h1.g, B, 0, s, &q1))) return r;
   // skip path
   if (b.skip == SK_CONV) {
     TV sin = (b.up || b.down) ? b.skin.v : b.x.v;
@@ -671,16 +703,17 @@ static int block_bwd(pu_ctx* c, Block& b, int B, int train, uint64_t seed, bool 
     // else (identity skip, 16-bit engines): dout is added inside the pass 2 of norm0's backward below
   }
   // norm1 (+scale/shift, dropout) -> c0.g
-  if ((r = gn_bwd<T>(c, b.n1, b.c0.v, b.h1.v, b.h1.g, b.c0.g, 0, B, train, seed, s))) return r;
+  if ((r = gn_bwd<T>(c, b.n1, b.c0.v, b.h1.v, b.h1.g, b.c0.g, 0, B, train, seed, s, nullptr, q1.slots))) return r;
   // conv0
   if ((r = conv_wgrad<T>(c, b.conv0, b.c0.g, b.a0.v, B, s, G(c, b.conv0.b_off), nullptr))) return r;
-  if ((r = conv_dgrad<T>(c, b.conv0, b.c0.g, b.a0.g, B, 0, s))) return r;
+  GnbReq q0; q0.n = &b.n0; q0.x = b.x.v; q0.train = train; q0.seed = seed;
+  if ((r = conv_dgrad<T>(c, b.conv0, b.c0.g, b.a0.g, B, 0, s, &q0))) return r;
   // norm0 (+resample) -> x.g   (parameter gradients are needed even when dx is not)
   TV dx = b.x.g; int acc = 0;
   if (need_dx) acc = take_acc(c, b.x);
   else { dx = with_b(b.x.v, B); dx.p = c->dv_scratch.p; dx.ld = b.x.v.C; }      // never happens for blocks (x always needs grad)
   const bool fold_skip = need_dx && b.skip == SK_IDENTITY && b.n0.resample == RS_NONE && sizeof(T) != 4;
-  return gn_bwd<T>(c, b.n0, b.x.v, b.a0.v, b.a0.g, dx, acc, B, train, seed, s, fold_skip ? &dout : nullptr);
+  return gn_bwd<T>(c, b.n0, b.x.v, b.a0.v, b.a0.g, dx, acc, B, train, seed, s, fold_skip ? &dout : nullptr, q0.slots);
 }
 
 template <typename T>
@@ -703,8 +736,9 @@ static int unet_backward(pu_ctx* c, hipStream_t s, Mid&& mid) {
   std::fill(c->flags.begin(), c->flags.end(), 0);
   Act& last = c->dec.back().out;
   if ((r = conv_wgrad<T>(c, c->out_conv, c->feat.g, c->out_a.v, B, s, G(c, c->out_conv.b_off), nullptr))) return r;
-  if ((r = conv_dgrad<T>(c, c->out_conv, c->feat.g, c->out_a.g, B, 0, s))) return r;
-  if ((r = gn_bwd<T>(c, c->out_norm, last.v, c->out_a.v, c->out_a.g, last.g, take_acc(c, last), B, train, seed, s))) return r;
+  GnbReq qo; qo.n = &c->out_norm; qo.x = last.v; qo.train = train; qo.seed = seed;
+  if ((r = conv_dgrad<T>(c, c->out_conv, c->feat.g, c->out_a.g, B, 0, s, &qo))) return r;
+  if ((r = gn_bwd<T>(c, c->out_norm, last.v, c->out_a.v, c->out_a.g, last.g, take_acc(c, last), B, train, seed, s, nullptr, qo.slots))) return r;
   const int jmid = (int)c->dec.size() * 2 / 3;           // `mid` is enqueued after the first third of the decoder blocks
   for (int j = (int)c->dec.size() - 1; j >= 0; --j) {
     if ((r = block_bwd<T>(c, c->dec[j], B, train, seed, true, s))) return r;
@@ -789,6 +823,7 @@ int pu_create(const pu_config* cfg, int device, pu_ctx** out) {
     return bail(PU_ERR_INVALID);
   }
   if (cfg->dropout_p < 0.f || cfg->dropout_p >= 1.f) { c->err = "bad dropout_p"; return bail(PU_ERR_INVALID); }
+  if (const char* e = getenv("PU_GN_FUSE_BWD_MINHW")) c->fuse_bwd_minhw = atol(e);
   c->planning = true;
   int r = build_plan(c);
   if (r != PU_OK) return bail(r);
@@ -814,8 +849,30 @@ int pu_create(const pu_config* cfg, int device, pu_ctx** out) {
   if ((e = hipMemcpy(c->descs_dev, c->descs.data(), c->descs.size() * sizeof(PackDesc), hipMemcpyHostToDevice)) != hipSuccess) {
     c->err = "hipMemcpy(descs)"; (void)hipFree(c->arena); (void)hipFree(c->packed); (void)hipFree(c->descs_dev); return bail(PU_ERR_HIP);
   }
-  if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) c->side = nullptr;
-  if (hipStreamCreateWithFlags(&c->side2, hipStreamNonBlocking) != hipSuccess) c->side2 = nullptr;
+  {
+    // complement of the convolution parameter ranges inside [0, nparams)
+    std::vector<std::pair<int64_t, int64_t>> cr = c->conv_ranges;
+    std::sort(cr.begin(), cr.end());
+    std::vector<long> zr; int64_t pos = 0;
+    for (auto& q : cr) { if (q.first > pos) { zr.push_back((long)pos); zr.push_back((long)q.first); } if (q.second > pos) pos = q.second; }
+    if (pos < c->nparams) { zr.push_back((long)pos); zr.push_back((long)c->nparams); }
+    c->n_zero_ranges = (int)zr.size() / 2;
+    if (c->n_zero_ranges > 0) {
+      if ((e = hipMalloc(&c->zero_ranges_dev, zr.size() * sizeof(long))) != hipSuccess ||
+          (e = hipMemcpy(c->zero_ranges_dev, zr.data(), zr.size() * sizeof(long), hipMemcpyHostToDevice)) != hipSuccess) {
+        c->err = "zero-range table"; (void)hipFree(c->arena); (void)hipFree(c->packed); (void)hipFree(c->descs_dev); return bail(PU_ERR_HIP);
+      }
+    }
+  }
+  {
+    // the engine's side streams (weight gradients, latent encoders) get the HIGHEST stream priority: whatever shares the GPU with them at
+    // default priority - in particular RCCL's reduction kernels of the bucketed gradient all-reduce, which run on torch's
+    // communication stream while the rest of the backward is still being computed - yields to the compute kernels at dispatch
+    int prio_least = 0, prio_greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess) { prio_least = prio_greatest = 0; (void)hipGetLastError(); }
+    if (hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, prio_greatest) != hipSuccess) { c->side = nullptr; (void)hipGetLastError(); }
+    if (hipStreamCreateWithPriority(&c->side2, hipStreamNonBlocking, prio_greatest) != hipSuccess) { c->side2 = nullptr; (void)hipGetLastError(); }
+  }
 
   if (c->side) {
     c->evs.resize(256);
@@ -841,6 +898,7 @@ int pu_destroy(pu_ctx* c) {
   if (c->arena) (void)(void)hipFree(c->arena);
   if (c->packed) (void)(void)hipFree(c->packed);
   if (c->descs_dev) (void)(void)hipFree(c->descs_dev);
+  if (c->zero_ranges_dev) (void)hipFree(c->zero_ranges_dev);
   delete c;
   return PU_OK;
 }
@@ -1085,7 +1143,12 @@ int pu_elbo_fwd_bwd(pu_ctx* c, const float* x, const float* target, const float*
     if (out_kl2) CKH(hipMemcpyAsync(out_kl2, c->kl2, (size_t)B * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (!with_backward) return PU_OK;
     // ---------------- backward
-    CKH(hipMemsetAsync(c->grads, 0, (size_t)c->nparams * sizeof(float), s));
+    static const bool full_memset = getenv("PU_GRAD_MEMSET") != nullptr;      // diagnostic: the round-2 behaviour (zero everything, accumulate)
+    struct OverwriteScope { pu_ctx* c; ~OverwriteScope() { c->grad_overwrite = false; } } ow_scope{c};
+    if (sizeof(T) == 2 && c->zero_ranges_dev && !full_memset) {
+      CKH(launch_zero_ranges(c->grads, c->zero_ranges_dev, c->n_zero_ranges, s));
+      c->grad_overwrite = true;                    // every convolution weight / bias is written exactly once below
+    } else CKH(hipMemsetAsync(c->grads, 0, (size_t)c->nparams * sizeof(float), s));
     FcombBwdArgs fb; memset(&fb, 0, sizeof fb);
     fb.f = fa; fb.dout = c->dpreds; fb.dfeat = with_b(c->feat.g, B); fb.dfeat_accumulate = 0; fb.dz = c->dz;
     fb.dw0 = G(c, c->fc_w0); fb.db0 = G(c, c->fc_b0); fb.dw1 = G(c, c->fc_w1); fb.db1 = G(c, c->fc_b1); fb.dw2 = G(c, c->fc_w2); fb.db2 = G(c, c->fc_b2);
@@ -1259,6 +1322,10 @@ int pu_grad_bucket_wait(pu_ctx* c, int k, void* stream) {
   if (!q.rec[0]) FAIL(PU_ERR_STATE, "bucket %d has not been recorded: call pu_elbo_fwd_bwd(with_backward) first", k);
   for (int i = 0; i < 3; ++i) if (q.rec[i]) CKH(hipStreamWaitEvent((hipStream_t)stream, q.ev[i], 0));
   return PU_OK;
+}
+int pu_scale_grads(float* g, int64_t n, const float* scale_dev, float host_factor, void* stream) {
+  if (!g || n < 0) return PU_ERR_INVALID;
+  return launch_scale_grads(g, (long)n, scale_dev, host_factor, (hipStream_t)stream) == hipSuccess ? PU_OK : PU_ERR_HIP;
 }
 int pu_nonfinite_flag(const float* g, int64_t n, float* flag, void* stream) {
   if (!g || !flag || n < 0) return PU_ERR_INVALID;

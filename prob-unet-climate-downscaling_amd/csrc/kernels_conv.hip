@@ -337,6 +337,131 @@ static inline void stat_resolve(ConvArgs& a, int slots) {
   if (a.stat_slots) *a.stat_slots = slots;
 }
 
+
+// host side: the data-gradient epilogue that writes dv + pass-1 rows (GNBwdFuse) exists in the conv3 / conv3p kernels only and excludes
+// every other epilogue option; report the slot count, or switch the request off (the kernel then stores the plain gradient)
+static inline void gnb_resolve(ConvArgs& a, int slots) {
+  if (a.gnb.slots) *a.gnb.slots = 0;
+  if (!a.gnb.x) return;
+  if (slots > a.gnb.cap || a.bias || a.res || a.relu || a.accumulate || a.stat_out || !a.gnb.part || !a.gnb.coef || a.gnb.C != a.Cout) { a.gnb.x = nullptr; return; }
+  if (a.gnb.slots) *a.gnb.slots = slots;
+}
+
+// ---- second half of the conv3 / conv3p epilogue: the wave's output tile sits in its private LDS staging tile [pixel][32 couts]
+// (ERS-element rows); each lane takes (pixel, 8-cout chunk) vectors: residual / accumulate / ReLU in the 16-byte domain, 64-byte
+// coalesced runs per pixel, plus either the GroupNorm statistics of the stored values (forward producers) or, for a data gradient that
+// feeds a GroupNorm backward (a.gnb), the pre-activation gradient dv and its pass-1 rows (see GNBwdFuse).
+template <typename T, int NTM, int TW, int TH, int WM, bool GNB>
+__device__ __forceinline__ void conv3_epilogue_store(const ConvArgs& a, const T* stage, int l, int wm, int ct, int b, int ty0, int tx0,
+                                                     int tiles_x, int tiles_y) {
+  constexpr int ERS = 40;
+  constexpr int NIT = NTM * 2;
+  T* out = reinterpret_cast<T*>(a.out);
+  const T* res = reinterpret_cast<const T*>(a.res);
+  float s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
+  const int ch = l & 3;
+  const int co = ct * 32 + ch * 8;
+  const int slots = tiles_x * tiles_y * WM;
+  const int slot = ((ty0 / TH) * tiles_x + tx0 / TW) * WM + wm;
+  if constexpr (GNB) {
+    // ---- data gradient -> dv of the preceding GroupNorm + SiLU (+ dropout), pass-1 rows
+    const T* gx = reinterpret_cast<const T*>(a.gnb.x);
+    const bool okc = co < a.Cout;
+    V16 xr[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {                          // every x vector in flight before the first use
+      const int pw = (it * 64 + l) >> 2;
+      const int m = wm * NTM * 32 + pw;
+      const size_t pix = (size_t)(b * a.H + ty0 + m / TW) * a.W + tx0 + m % TW;
+      xr[it] = *reinterpret_cast<const V16*>(gx + pix * a.gnb.x_ld + (okc ? co : 0));
+    }
+    float cA[8], cB[8], cM[8];
+    const float4* cf = reinterpret_cast<const float4*>(a.gnb.coef) + ((size_t)b * a.Cout + (okc ? co : 0));
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { const float4 q = cf[e]; cA[e] = q.x; cB[e] = q.y; cM[e] = q.z; }
+    const float dp = a.gnb.drop.drop_p, keep = 1.f - dp, inv_keep = dp > 0.f ? 1.f / keep : 1.f;
+    const uint32_t dkey = drop_key(a.gnb.drop.seed, a.gnb.drop.stream), dthr = drop_thr16(keep);
+    const uint64_t HW = (uint64_t)a.H * a.W;
+    // keep decisions: saved by the forward (one byte per vector; the usual case), else re-derived (hash stream / injected mask).
+    // All loaded / computed before the arithmetic so that the loop below is one straight-line block per vector.
+    uint32_t kbs[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) kbs[it] = 0xffu;
+    if (dp > 0.f && okc) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int m = wm * NTM * 32 + ((it * 64 + l) >> 2);
+        const uint64_t base = ((uint64_t)(b + a.gnb.drop.b0) * HW + (uint64_t)(ty0 + m / TW) * a.W + (tx0 + m % TW)) * (uint64_t)a.Cout + (uint64_t)co;
+        kbs[it] = a.gnb.drop.bits ? (uint32_t)a.gnb.drop.bits[base >> 3] : drop_keep_bits8(a.gnb.drop.mask, dkey, dthr, base);
+      }
+    }
+    if (okc) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int pw = (it * 64 + l) >> 2;
+        const int m = wm * NTM * 32 + pw;
+        const size_t pix = (size_t)(b * a.H + ty0 + m / TW) * a.W + tx0 + m % TW;
+        float v[8], xv[8];
+        unpack<T>(*reinterpret_cast<const V16*>(stage + pw * ERS + ch * 8), v);
+        unpack<T>(xr[it], xv);
+        const uint32_t kb = kbs[it];
+        float d[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          d[e] = xv[e] - cM[e];
+          const float dh = ((kb >> e) & 1u) ? v[e] * inv_keep : 0.f;
+          v[e] = dh * dsilu_f<false>(cA[e] * d[e] + cB[e]);
+        }
+        const V16 pk = pack<T>(v);
+        *reinterpret_cast<V16*>(out + pix * a.out_ld + co) = pk;
+        float w[8]; unpack<T>(pk, w);                            // sums of the values as stored (what pass 2 reads)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s1[e] += w[e]; s2[e] += w[e] * d[e]; }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s2[e] *= cf[e].w;                // S2 = rstd * sum dv (x - mean): rstd is constant per (sample, channel)
+    wave_stat_store(s1, s2, l, a.gnb.part + (((size_t)b * slots + slot) * a.Cout + co) * 2, okc);
+    return;
+  }
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int i = it * 64 + l;                               // (pixel of the wave, 8-cout chunk)
+    const int pw = i >> 2;
+    const int m = wm * NTM * 32 + pw;
+    const int gy = ty0 + m / TW, gx = tx0 + m % TW;
+    const size_t pix = (size_t)(b * a.H + gy) * a.W + gx;
+    if (co < a.Cout) {
+      float v[8];
+      unpack<T>(*reinterpret_cast<const V16*>(stage + pw * ERS + ch * 8), v);
+      if (res) {
+        float r[8]; unpack<T>(*reinterpret_cast<const V16*>(res + pix * a.res_ld + co), r);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += r[e];
+      }
+      if (a.accumulate) {
+        float r[8]; unpack<T>(*reinterpret_cast<const V16*>(out + pix * a.out_ld + co), r);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += r[e];
+      }
+      if (a.relu) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+      }
+      const V16 pk = pack<T>(v);
+      if (!(PU_ABLATE & 16) || pk.w[0] == 0x12345678u) *reinterpret_cast<V16*>(out + pix * a.out_ld + co) = pk;
+      if (a.stat_out) {                                      // statistics of the values as stored (rounded to T)
+        float w[8]; unpack<T>(pk, w);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s1[e] += w[e]; s2[e] += w[e] * w[e]; }
+      }
+    }
+  }
+  if (a.stat_out) wave_stat_store(s1, s2, l, a.stat_out + (((size_t)b * slots + slot) * a.Cout + co) * 2, co < a.Cout);
+}
+
 // ------------------------------------------------------------------ conv3: cout-split waves, weights straight to registers
 // 16-bit only.  Block = 4 waves; wave (wm, wn) owns NTM 32-pixel columns x ONE 32-cout row tile, so its A (weight)
 // fragments are private: they are read from the fragment-major packed buffer with one fully coalesced 1-KiB load per
@@ -347,7 +472,9 @@ static inline void stat_resolve(ConvArgs& a, int slots) {
 // cycle, but the chip holds a higher clock on it under load, MI355X_MICROARCH.md "DVFS give-back" item 7).  The MS = 16 form reads
 // [pixel][32 ch] LDS rows of 96 bytes (conflict-free for the lane -> (pixel = l & 15, 8 channels at 8 (l >> 4)) fragment) and
 // weights packed as [cout tile][chunk][tap][cout half][lane][8] (PackDesc mode bit 2).
-template <typename T, int KS, int TH, int TW, int WM, int WN, int MS = 32>
+// GNB: the epilogue of a data gradient that feeds a GroupNorm backward (GNBwdFuse) - its own instantiation, so that the register
+// allocation of the plain kernel is untouched
+template <typename T, int KS, int TH, int TW, int WM, int WN, int MS = 32, bool GNB = false>
 __global__ __launch_bounds__(64 * WM * WN, (MS == 16 && TH * TW / WM <= 128) ? 2 : 1) void conv3_kernel(ConvArgs a) {
   typedef MM<T> M;
   constexpr int NT = 64 * WM * WN;
@@ -577,51 +704,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MS == 16 && TH * TW / WM <= 128) ? 2
       }
     }
   }
-  T* out = reinterpret_cast<T*>(a.out);
-  const T* res = reinterpret_cast<const T*>(a.res);
-  float s1[8], s2[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
-#pragma unroll
-  for (int it = 0; it < NTM * 2; ++it) {
-    const int i = it * 64 + l;                               // (pixel of the wave, 8-cout chunk)
-    const int pw = i >> 2, ch = i & 3;
-    const int m = wm * NTM * 32 + pw;
-    const int gy = ty0 + m / TW, gx = tx0 + m % TW;
-    const size_t pix = (size_t)(b * a.H + gy) * a.W + gx;
-    const int co = ct * 32 + ch * 8;
-    if (co < a.Cout) {
-      float v[8];
-      unpack<T>(*reinterpret_cast<const V16*>(stage + pw * ERS + ch * 8), v);
-      if (res) {
-        float r[8]; unpack<T>(*reinterpret_cast<const V16*>(res + pix * a.res_ld + co), r);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += r[e];
-      }
-      if (a.accumulate) {
-        float r[8]; unpack<T>(*reinterpret_cast<const V16*>(out + pix * a.out_ld + co), r);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += r[e];
-      }
-      if (a.relu) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
-      }
-      const V16 pk = pack<T>(v);
-      if (!(PU_ABLATE & 16) || pk.w[0] == 0x12345678u) *reinterpret_cast<V16*>(out + pix * a.out_ld + co) = pk;
-      if (a.stat_out) {                                      // statistics of the values as stored (rounded to T)
-        float w[8]; unpack<T>(pk, w);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { s1[e] += w[e]; s2[e] += w[e] * w[e]; }
-      }
-    }
-  }
-  if (a.stat_out) {
-    const int slots = tiles_x * tiles_y * WM;
-    const int slot = ((ty0 / TH) * tiles_x + tx0 / TW) * WM + wm;
-    const int co = ct * 32 + (l & 3) * 8;
-    wave_stat_store(s1, s2, l, a.stat_out + (((size_t)b * slots + slot) * a.Cout + co) * 2, co < a.Cout);
-  }
+  conv3_epilogue_store<T, NTM, TW, TH, WM, GNB>(a, stage, l, wm, ct, b, ty0, tx0, tiles_x, tiles_y);
 #if PU_ABLATE & 32
   {
     const uint64_t ts3 = __builtin_amdgcn_s_memtime(), tr3 = __builtin_amdgcn_s_memrealtime();
@@ -642,8 +725,8 @@ __global__ __launch_bounds__(64 * WM * WN, (MS == 16 && TH * TW / WM <= 128) ? 2
 // fragments in registers (NCH x taps x 2 fragments, loaded once), walks over many pixel tiles, and software-pipelines them:
 // the halo tile of tile t+1 is in flight (global -> registers) during the MFMAs of tile t and lands in the other LDS buffer
 // afterwards; the epilogue stores of tile t drain under the MFMAs of tile t+1.  One barrier per tile.
-template <typename T, int KS, int TH, int TW, int WM, int WN, int NCH>
-__global__ __launch_bounds__(64 * WM * WN) void conv3p_kernel(ConvArgs a) {
+template <typename T, int KS, int TH, int TW, int WM, int WN, int NCH, bool GNB = false>
+__global__ __launch_bounds__(64 * WM * WN, (GNB && NCH == 1 && WN == 1) ? 2 : 1) void conv3p_kernel(ConvArgs a) {
   typedef MM<T> M;
   constexpr int NT = 64 * WM * WN;
   constexpr int BM = TH * TW;
@@ -681,11 +764,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3p_kernel(ConvArgs a) {
         u.v = *reinterpret_cast<const V16*>(wbase + ((size_t)(c * TAPS + t) * 2 + kk) * 512);
         fa[c][t][kk] = u.f;
       }
-  float bq[16];
+  float bq[GNB ? 1 : 16];                                     // (a data gradient has no bias)
+  if constexpr (!GNB) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
-    bq[r] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
+    for (int r = 0; r < 16; ++r) {
+      const int co = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+      bq[r] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
+    }
   }
   int pbase[NTM];
 #pragma unroll
@@ -731,8 +816,6 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3p_kernel(ConvArgs a) {
     }
   };
 
-  T* out = reinterpret_cast<T*>(a.out);
-  const T* res = reinterpret_cast<const T*>(a.res);
   // XCD-aware walk: block b handles tiles b, b + G, ...; neighbouring blocks work on neighbouring tiles at the same time
   int tile = blockIdx.x;
   int cur = 0;
@@ -745,7 +828,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3p_kernel(ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < NTM; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[j][r] = bq[r];
+      for (int r = 0; r < 16; ++r) acc[j][r] = GNB ? 0.f : bq[GNB ? 0 : r];
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
       const T* sb = sIn + cur * BUF + c * CHB;
@@ -776,49 +859,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv3p_kernel(ConvArgs a) {
           store4<T>(stage + (j * 32 + (l & 31)) * ERS + 8 * q + 4 * (l >> 5), v);
         }
       }
-      float s1[8], s2[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
-#pragma unroll
-      for (int it = 0; it < NTM * 2; ++it) {
-        const int i = it * 64 + l;
-        const int pw = i >> 2, ch = i & 3;
-        const int m = wm * NTM * 32 + pw;
-        const int gy = ty0 + m / TW, gx = tx0 + m % TW;
-        const size_t pix = (size_t)(b * a.H + gy) * a.W + gx;
-        const int co = ct * 32 + ch * 8;
-        if (co < a.Cout) {
-          float v[8];
-          unpack<T>(*reinterpret_cast<const V16*>(stage + pw * ERS + ch * 8), v);
-          if (res) {
-            float r[8]; unpack<T>(*reinterpret_cast<const V16*>(res + pix * a.res_ld + co), r);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += r[e];
-          }
-          if (a.accumulate) {
-            float r[8]; unpack<T>(*reinterpret_cast<const V16*>(out + pix * a.out_ld + co), r);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += r[e];
-          }
-          if (a.relu) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
-          }
-          const V16 pk = pack<T>(v);
-          *reinterpret_cast<V16*>(out + pix * a.out_ld + co) = pk;
-          if (a.stat_out) {
-            float w[8]; unpack<T>(pk, w);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { s1[e] += w[e]; s2[e] += w[e] * w[e]; }
-          }
-        }
-      }
-      if (a.stat_out) {
-        const int slots = tiles_x * tiles_y * WM;
-        const int slot = ((ty0 / TH) * tiles_x + tx0 / TW) * WM + wm;
-        const int co = ct * 32 + (l & 3) * 8;
-        wave_stat_store(s1, s2, l, a.stat_out + (((size_t)b * slots + slot) * a.Cout + co) * 2, co < a.Cout);
-      }
+      conv3_epilogue_store<T, NTM, TW, TH, WM, GNB>(a, stage, l, wm, ct, b, ty0, tx0, tiles_x, tiles_y);
     }
     if (nxt < ntiles) lstore(cur ^ 1);
     __syncthreads();
@@ -830,16 +871,19 @@ template <typename T, int KS, int TH, int TW, int WM, int WN, int NCH>
 static hipError_t launch_conv3p_cfg(const ConvArgs& a0, hipStream_t s) {
   ConvArgs a = a0;
   stat_resolve(a, (a.W / TW) * (a.H / TH) * WM);
+  if (KS != 3) a.gnb.x = nullptr;                             // the dv epilogue is instantiated for the 3x3 kernels only
+  gnb_resolve(a, (a.W / TW) * (a.H / TH) * WM);
   constexpr int TAPS = KS * KS, PADP = KS / 2;
   constexpr int IH = TH + 2 * PADP, IW = TW + 2 * PADP, KCP = KC + MM<T>::PAD, BN = 32 * WN;
   constexpr size_t lds = ((size_t)2 * NCH * IH * IW * KCP + (size_t)(TH * TW / (32 * WM)) * 32 * 40 * WM * WN) * sizeof(T);
   static_assert(lds <= 160 * 1024, "conv3p LDS");
-  auto kern = conv3p_kernel<T, KS, TH, TW, WM, WN, NCH>;
-  static AttrOnce attr_once;
-  if (!attr_once.cur()) {
+  void (*kern)(ConvArgs) = conv3p_kernel<T, KS, TH, TW, WM, WN, NCH>;
+  if constexpr (KS == 3) { if (a.gnb.x) kern = conv3p_kernel<T, KS, TH, TW, WM, WN, NCH, true>; }
+  static AttrOnce attr_once[2];
+  if (!attr_once[a.gnb.x ? 1 : 0].cur()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    attr_once.cur() = true;
+    attr_once[a.gnb.x ? 1 : 0].cur() = true;
   }
   const int ntiles = (a.W / TW) * (a.H / TH) * a.B;
   const int gy = cdiv(a.Cout, BN);
@@ -849,7 +893,7 @@ static hipError_t launch_conv3p_cfg(const ConvArgs& a0, hipStream_t s) {
   char tag[128];
   const bool prof = prof_enabled();
   if (prof) {
-    snprintf(tag, sizeof tag, "conv3p_kernel<%s,%d,%d,%d,%d,%d,%d>", ET<T>::DT == 1 ? "f16" : "bf16", KS, TH, TW, WM, WN, NCH);
+    snprintf(tag, sizeof tag, "conv3p_kernel<%s,%d,%d,%d,%d,%d,%d%s>", ET<T>::DT == 1 ? "f16" : "bf16", KS, TH, TW, WM, WN, NCH, a.gnb.x ? ",1" : "");
     const double px = (double)a.B * a.H * a.W;
     prof_record(tag, 2.0 * px * a.Cout * (double)a.Cin * TAPS, px * (a.Cin + a.Cout) * sizeof(T) + (double)a.Cout * a.Cin * TAPS * sizeof(T), s, true);
   }
@@ -876,25 +920,27 @@ static hipError_t launch_conv3_cfg(const ConvArgs& a0, hipStream_t s) {
   }
   ConvArgs a = a0;
   stat_resolve(a, (a.W / TW) * (a.H / TH) * WM);
+  if (KS != 3) a.gnb.x = nullptr;                             // the dv epilogue is instantiated for the 3x3 kernels only
+  gnb_resolve(a, (a.W / TW) * (a.H / TH) * WM);
   constexpr int TAPS = KS * KS, PADP = KS / 2;
   constexpr int IH = TH + 2 * PADP, IW = TW + 2 * PADP, KCP = KC + (MS == 16 ? 16 : MM<T>::PAD), BN = 32 * WN;
   (void)TAPS;
   constexpr size_t lds_in = (size_t)2 * IH * IW * KCP * sizeof(T);
   constexpr size_t lds_ep = (size_t)(TH * TW / (32 * WM)) * 32 * 40 * WM * WN * sizeof(T);      // epilogue staging, wave-private
   constexpr size_t lds = lds_in > lds_ep ? lds_in : lds_ep;
-  auto kern = conv3_kernel<T, KS, TH, TW, WM, WN, MS>;
-  static AttrOnce attr_once;
-  if (!attr_once.cur()) {
+  void (*kern)(ConvArgs) = conv3_kernel<T, KS, TH, TW, WM, WN, MS>;
+  if constexpr (KS == 3) { if (a.gnb.x) kern = conv3_kernel<T, KS, TH, TW, WM, WN, MS, true>; }
+  static AttrOnce attr_once[2];
+  if (!attr_once[a.gnb.x ? 1 : 0].cur()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    attr_once.cur() = true;
+    attr_once[a.gnb.x ? 1 : 0].cur() = true;
   }
   dim3 grid((unsigned)((a.W / TW) * (a.H / TH) * a.B), (unsigned)cdiv(a.Cout, BN));
   char tag[128];
   const bool prof = prof_enabled();
   if (prof) {
-    if (MS == 32) snprintf(tag, sizeof tag, "conv3_kernel<%s,%d,%d,%d,%d,%d>", ET<T>::DT == 1 ? "f16" : "bf16", KS, TH, TW, WM, WN);
-    else snprintf(tag, sizeof tag, "conv3_kernel<%s,%d,%d,%d,%d,%d,%d>", ET<T>::DT == 1 ? "f16" : "bf16", KS, TH, TW, WM, WN, MS);
+    snprintf(tag, sizeof tag, "conv3_kernel<%s,%d,%d,%d,%d,%d,%d%s>", ET<T>::DT == 1 ? "f16" : "bf16", KS, TH, TW, WM, WN, MS, a.gnb.x ? ",1" : "");
     const double px = (double)a.B * a.H * a.W;
     prof_record(tag, 2.0 * px * a.Cout * (double)a.Cin * TAPS, px * (a.Cin + a.Cout) * sizeof(T) + (double)a.Cout * a.Cin * TAPS * sizeof(T), s, true);
   }
@@ -985,6 +1031,7 @@ static hipError_t launch_ks(const ConvArgs& a, hipStream_t s) {
 template <typename T>
 hipError_t launch_conv(const ConvArgs& a, hipStream_t s) {
   if (a.stat_slots) *a.stat_slots = 0;             // only the conv3 / conv3p launchers produce fused statistics
+  if (a.gnb.slots) *a.gnb.slots = 0;               // ... and the dv epilogue of the GroupNorm backward
   if (a.frag_layout) {
     if (!conv_uses_frag_layout((int)sizeof(T), a.H, a.W)) return hipErrorInvalidValue;
     if (a.taps == 9) return launch_conv3<T, 3>(a, s);

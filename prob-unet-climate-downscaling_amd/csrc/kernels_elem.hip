@@ -13,9 +13,10 @@ namespace pu {
 // Keep decisions of the VEC consecutive elements starting at the dense NHWC index `base` of a dropout site: bit e set = keep.
 // The hash stream is the product path; an injected mask (uint8 NHWC, 1 = keep: pu_set_drop_masks, parity tests against the
 // oracle's drop_masks= path, networks.py:177) replaces it when present.
-template <int VEC>
+template <int VEC, bool SAVED = false>
 __device__ __forceinline__ uint32_t drop_keep_bits(const GNArgs& f, uint32_t dkey, uint32_t dthr, uint64_t base) {
   uint32_t bits = 0;
+  if (SAVED && VEC == 8 && f.keep_bits) return f.keep_bits[base >> 3];     // backward: the decisions the forward saved
   if (f.drop_mask) {
     if (VEC == 8) {
       const uint2 m = *reinterpret_cast<const uint2*>(f.drop_mask + base);
@@ -271,6 +272,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GNArgs a) {
           if (a.drop_p > 0.f) {
             const uint64_t base = ((uint64_t)(b + a.b0) * OHW + pp) * (uint64_t)C + (uint64_t)cv * VEC;
             const uint32_t kb = drop_keep_bits<VEC>(a, dkey, dthr, base);
+            if (VEC == 8 && a.keep_bits) a.keep_bits[base >> 3] = (uint8_t)kb;
 #pragma unroll
             for (int e = 0; e < VEC; ++e) o[e] = ((kb >> e) & 1u) ? o[e] * inv_keep : 0.f;
           }
@@ -435,7 +437,7 @@ __device__ __forceinline__ void gn_dv_math(const GNArgs& f, const DyRaw<T, RS>& 
   if (RS == RS_NONE && f.drop_p > 0.f) {
     const uint32_t dkey = drop_key(f.drop_seed, f.drop_stream), dthr = drop_thr16(keep);
     const uint64_t base = ((uint64_t)(b + f.b0) * HW + p) * (uint64_t)C + (uint64_t)(cv * VEC);
-    const uint32_t kb = drop_keep_bits<VEC>(f, dkey, dthr, base);
+    const uint32_t kb = drop_keep_bits<VEC, true>(f, dkey, dthr, base);
 #pragma unroll
     for (int e = 0; e < VEC; ++e) dh[e] = ((kb >> e) & 1u) ? dh[e] * inv_keep : 0.f;
   }
@@ -489,7 +491,7 @@ __global__ __launch_bounds__(256) void gn_bwd_pass1_kernel(GNBwdArgs a) {
             unpack<T>(rx[u], xv); unpack<T>(rd[u], dh);
             if (f.drop_p > 0.f) {
               const uint64_t base = ((uint64_t)(b + f.b0) * HW + pp) * (uint64_t)C + (uint64_t)(cv * VEC);
-              const uint32_t kb = drop_keep_bits<VEC>(f, dkey, dthr, base);
+              const uint32_t kb = drop_keep_bits<VEC, true>(f, dkey, dthr, base);
 #pragma unroll
               for (int e = 0; e < VEC; ++e) dh[e] = ((kb >> e) & 1u) ? dh[e] * inv_keep : 0.f;
             }
@@ -548,8 +550,8 @@ __global__ __launch_bounds__(NT) void gn_bwd_finalize_kernel(GNBwdArgs a) {
     // per-channel totals of the pass-1 rows: nl threads share a channel (with C = 32 a one-thread-per-channel loop would
     // leave 224 of the block's 256 threads idle behind 64 dependent loads)
     __shared__ float red[NT * 2];
-    const float2* part = reinterpret_cast<const float2*>(a.part2);
-    const int nk = f.nchunk;
+    const float2* part = reinterpret_cast<const float2*>(a.rows ? a.rows : a.part2);
+    const int nk = a.rows ? a.nrows : f.nchunk;
     const int nl = C >= NT ? 1 : NT / C;
     for (int c0 = 0; c0 < C; c0 += NT) {
       const int c = nl > 1 ? tid % C : c0 + tid, lane = nl > 1 ? tid / C : 0;
@@ -597,7 +599,8 @@ __global__ __launch_bounds__(NT) void gn_bwd_finalize_kernel(GNBwdArgs a) {
   }
 }
 
-template <typename T, int RS>
+// DV: `dy` already holds dv (written by the data-gradient epilogue, GNBwdFuse): no mask, no silu' - two reads, two FMAs per element
+template <typename T, int RS, bool DV = false>
 __global__ __launch_bounds__(256) void gn_bwd_pass2_kernel(GNBwdArgs a) {
   constexpr int VEC = ET<T>::VEC;
   const GNArgs& f = a.f;
@@ -638,9 +641,9 @@ __global__ __launch_bounds__(256) void gn_bwd_pass2_kernel(GNBwdArgs a) {
         if (pp < p1) {
           float xv[VEC], dh[VEC], o[VEC];
           unpack<T>(rx[u], xv); unpack<T>(rd[u], dh);
-          if (f.drop_p > 0.f) {
+          if (!DV && f.drop_p > 0.f) {
             const uint64_t base = ((uint64_t)(b + f.b0) * HW + pp) * (uint64_t)C + (uint64_t)(cv * VEC);
-            const uint32_t kb = drop_keep_bits<VEC>(f, dkey, dthr, base);
+            const uint32_t kb = drop_keep_bits<VEC, true>(f, dkey, dthr, base);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) dh[e] = ((kb >> e) & 1u) ? dh[e] * inv_keep : 0.f;
           }
@@ -657,7 +660,7 @@ __global__ __launch_bounds__(256) void gn_bwd_pass2_kernel(GNBwdArgs a) {
 #pragma unroll
           for (int e = 0; e < VEC; ++e) {
             const float d = xv[e] - mu[e];
-            const float dv = dh[e] * dsilu_f<sizeof(T) == 4>(A[e] * d + Bc[e]);
+            const float dv = DV ? dh[e] : dh[e] * dsilu_f<sizeof(T) == 4>(A[e] * d + Bc[e]);
             o[e] += c0[e] * dv + c1[e] * d + c2[e];
           }
           stv<T>(dxp + ((long)b * HW + pp) * a.dx.ld + cv * VEC, pack<T>(o));
@@ -737,7 +740,7 @@ __global__ __launch_bounds__(256) void gn_small_bwd_kernel(GNBwdArgs a, int CB) 
     unpack<T>(rx, xv); unpack<T>(rd, dh);
     if (f.drop_p > 0.f) {
       const uint64_t base = ((uint64_t)(b + f.b0) * HW + p) * (uint64_t)C + (uint64_t)(c0 + cv * VEC);
-      const uint32_t kb = drop_keep_bits<VEC>(f, dkey, dthr, base);
+      const uint32_t kb = drop_keep_bits<VEC, true>(f, dkey, dthr, base);
 #pragma unroll
       for (int e = 0; e < VEC; ++e) dh[e] = ((kb >> e) & 1u) ? dh[e] * inv_keep : 0.f;
     }
@@ -860,7 +863,9 @@ hipError_t launch_gn_bwd_parts(const GNBwdArgs& a, int parts, hipStream_t s) {
     }
     return hipGetLastError();
   }
-  if (parts & 1) {
+  const bool dvrows = a.rows != nullptr && a.nrows > 0;
+  if (dvrows && (f.resample != RS_NONE || sizeof(T) != 2)) return hipErrorInvalidValue;
+  if ((parts & 1) && !dvrows) {
     dim3 g1(f.nchunk, f.x.B);
     if (prof) gn_prof_begin("gn_bwd_pass1", f.resample, f.x, xb + dyb, s, a.dy.ld, a.dx.ld, (f.drop_p > 0.f) + 2 * a.accumulate + 4 * (a.add.p != nullptr));
     if (f.resample == RS_NONE) hipLaunchKernelGGL((gn_bwd_pass1_kernel<T, RS_NONE>), g1, dim3(256), 0, s, a);
@@ -871,8 +876,9 @@ hipError_t launch_gn_bwd_parts(const GNBwdArgs& a, int parts, hipStream_t s) {
   if (parts & 4) hipLaunchKernelGGL(gn_bwd_finalize_kernel<1024>, dim3(f.x.B), dim3(1024), 0, s, a);
   if (parts & 2) {
     const dim3 g2(gn_pix_blocks((long)f.x.H * f.x.W, f.x.C / ET<T>::VEC, f.x.B), f.x.B);
-    if (prof) gn_prof_begin("gn_bwd_pass2", f.resample, f.x, p2b, s, a.dy.ld, a.dx.ld, (f.drop_p > 0.f) + 2 * a.accumulate + 4 * (a.add.p != nullptr));
-    if (f.resample == RS_NONE) hipLaunchKernelGGL((gn_bwd_pass2_kernel<T, RS_NONE>), g2, dim3(256), 0, s, a);
+    if (prof) gn_prof_begin(dvrows ? "gn_bwd_pass2_dv" : "gn_bwd_pass2", f.resample, f.x, p2b, s, a.dy.ld, a.dx.ld, (f.drop_p > 0.f) + 2 * a.accumulate + 4 * (a.add.p != nullptr));
+    if (dvrows) hipLaunchKernelGGL((gn_bwd_pass2_kernel<T, RS_NONE, true>), g2, dim3(256), 0, s, a);
+    else if (f.resample == RS_NONE) hipLaunchKernelGGL((gn_bwd_pass2_kernel<T, RS_NONE>), g2, dim3(256), 0, s, a);
     else if (f.resample == RS_DOWN) hipLaunchKernelGGL((gn_bwd_pass2_kernel<T, RS_DOWN>), g2, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((gn_bwd_pass2_kernel<T, RS_UP>), g2, dim3(256), 0, s, a);
     if (prof) prof_record("", 0, 0, s, false);
@@ -891,6 +897,12 @@ hipError_t launch_gn_bwd(const GNBwdArgs& a0, hipStream_t s) {
     a.add = tv_batch(a0.add, b0, nb, sizeof(T));
     a.part2 = a0.part2 + (size_t)b0 * a0.f.nchunk * a0.f.x.C * 2; a.coef2 = a0.coef2 + (size_t)b0 * a0.f.x.C * 3;
     int cb = 0;
+    if (a0.rows && a0.nrows > 0) {
+      if (step != a0.f.x.B) return hipErrorInvalidValue;                       // (the rows are laid out for the whole batch)
+      hipError_t e2 = launch_gn_bwd_parts<T>(a, 6, s);                          // coefficients from the rows + pass 2 on dv
+      if (e2 != hipSuccess) return e2;
+      continue;
+    }
     hipError_t e = launch_gn_bwd_parts<T>(a, gn_bwd_is_small<T>(a.f, &cb) ? 8 : 7, s);
     if (e != hipSuccess) return e;
   }
@@ -1463,6 +1475,31 @@ __global__ __launch_bounds__(256) void nonfinite_flag_kernel(const float* __rest
     }
   }
   if (__any(bad) && (threadIdx.x & 63) == 0) flag[0] = 1.f;
+}
+// g[lo .. hi) = 0 for every range of the table (the parameter gradients that are ACCUMULATED by their kernels: GroupNorm / Fcomb /
+// head parameters, dead parameters; the convolution weights and biases are written, not accumulated, in the fused ELBO backward)
+__global__ __launch_bounds__(256) void zero_ranges_kernel(float* __restrict__ g, const long* __restrict__ ranges) {
+  const long lo = ranges[2 * blockIdx.y], hi = ranges[2 * blockIdx.y + 1];
+  for (long i = lo + (long)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += (long)gridDim.x * blockDim.x) g[i] = 0.f;
+}
+hipError_t launch_zero_ranges(float* g, const long* ranges_dev, int n, hipStream_t s) {
+  if (n > 0) hipLaunchKernelGGL(zero_ranges_kernel, dim3(16, n), dim3(256), 0, s, g, ranges_dev);
+  return hipGetLastError();
+}
+// g *= host_factor * (scale_dev ? scale_dev[0] : 1), skipped entirely (one load per thread) when that factor is exactly 1: the
+// grad_output of loss.backward() is almost always the scalar 1, known only on the device
+__global__ __launch_bounds__(256) void scale_grads_kernel(float* __restrict__ g, long n, const float* __restrict__ scale_dev, float host_factor) {
+  const float f = host_factor * (scale_dev ? scale_dev[0] : 1.f);
+  if (f == 1.f) return;
+  for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long)gridDim.x * blockDim.x * 4) {
+    if (i + 4 <= n) { f32x4 v = *reinterpret_cast<f32x4*>(g + i); v *= f; *reinterpret_cast<f32x4*>(g + i) = v; }
+    else for (long k = i; k < n; ++k) g[k] *= f;
+  }
+}
+hipError_t launch_scale_grads(float* g, long n, const float* scale_dev, float host_factor, hipStream_t s) {
+  if ((reinterpret_cast<uintptr_t>(g) & 15) != 0) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(scale_grads_kernel, dim3(ew_grid((n + 3) / 4)), dim3(256), 0, s, g, n, scale_dev, host_factor);
+  return hipGetLastError();
 }
 hipError_t launch_nonfinite_flag(const float* g, long n, float* flag, hipStream_t s) {
   hipLaunchKernelGGL(nonfinite_flag_kernel, dim3(ew_grid((n + 3) / 4)), dim3(256), 0, s, g, n, flag);

@@ -361,11 +361,14 @@ __global__ __launch_bounds__(256) void fcomb_fwd16_kernel(FcombArgs f, const flo
   }
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void fcomb_bwd16_kernel(FcombBwdArgs a, const float* __restrict__ zb, float* __restrict__ dzb) {
+// NCO > 0: compact form for Cout = NCO <= 4 output planes (the downscaling configurations have 1 or 3): the last layer's backward
+// (W2^T . dout, dW2, db2) is 16 * NCO per-lane multiply-adds instead of padded MFMAs with one useful row, its operand tiles never
+// go through LDS, and the kernel fits two waves per SIMD.  NCO == 0: general form (any Cout <= 32).
+template <typename T, int NCO>
+__global__ __launch_bounds__(256, NCO > 0 ? 2 : 1) void fcomb_bwd16_kernel(FcombBwdArgs a, const float* __restrict__ zb, float* __restrict__ dzb) {
   typedef FCM<T> M;
   extern __shared__ __attribute__((aligned(16))) unsigned char fc16_smem[];
-  uint16_t* tiles = reinterpret_cast<uint16_t*>(fc16_smem);        // 6 x [128][32]: dout | h1 | dh1 | h0 | dh0 | feat
+  uint16_t* tiles = reinterpret_cast<uint16_t*>(fc16_smem);        // 6 x [128][32]: dout | h1 | dh1 | h0 | dh0 | feat  (NCO > 0: the first two unused)
   float* zbs = reinterpret_cast<float*>(fc16_smem + 6 * 128 * 32 * 2);   // [M][32]: this sample's per-member latent bias (L2 latency paid once)
   constexpr int CHP = 128, TS = CHP * 32;                          // pixels per chunk (4 waves x 32), tile stride
   const FcombArgs& f = a.f;
@@ -395,6 +398,15 @@ __global__ __launch_bounds__(256) void fcomb_bwd16_kernel(FcombBwdArgs a, const 
   f32x16 aw[3], as1, as2, az;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { aw[0][r] = 0.f; aw[1][r] = 0.f; aw[2][r] = 0.f; as1[r] = 0.f; as2[r] = 0.f; }
+  // compact last layer: W2 rows of this lane's channels, per-lane partial sums of dW2 / db2 over the lane's own pixels
+  constexpr int NC = NCO > 0 ? NCO : 1;
+  float w2r[NC][16], aw2v[NC][16], ab2v[NC];
+#pragma unroll
+  for (int co = 0; co < NC; ++co) {
+    ab2v[co] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { w2r[co][r] = (NCO > 0) ? f.w2[co * 32 + fc_row(r, h)] : 0.f; aw2v[co][r] = 0.f; }
+  }
   // transposed-read lane roles
   const int g = l >> 4, q = (l & 15) >> 2, p = l & 3;
   const int nchunks = (int)((HW + CHP - 1) / CHP);
@@ -405,8 +417,13 @@ __global__ __launch_bounds__(256) void fcomb_bwd16_kernel(FcombBwdArgs a, const 
   // form for Cout <= 4 (rows 0..3 live in the h == 0 half of both layouts); wider outputs load in place.
   const bool small_co = f.Cout <= 4;
   auto load_dout4 = [&](int m, long pix, bool valid, float* dn) {
+    if constexpr (NCO > 0) {                                 // both lane halves of a pixel need its dout values
 #pragma unroll
-    for (int e = 0; e < 4; ++e) dn[e] = (valid && small_co && h == 0 && e < f.Cout) ? a.dout[(((long)b * f.M + m) * f.Cout + e) * HW + pix] : 0.f;
+      for (int e = 0; e < 4; ++e) dn[e] = (valid && e < NCO) ? a.dout[(((long)b * f.M + m) * NCO + e) * HW + pix] : 0.f;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) dn[e] = (valid && small_co && h == 0 && e < f.Cout) ? a.dout[(((long)b * f.M + m) * f.Cout + e) * HW + pix] : 0.f;
+    }
   };
   // the feature rows of the NEXT chunk are fetched while the members of the current one are processed
   V16 nxf[2];
@@ -460,11 +477,25 @@ __global__ __launch_bounds__(256) void fcomb_bwd16_kernel(FcombBwdArgs a, const 
         acc = M::mfma(w.w1p[1], fc_acc_frag<T>(h0, 1), acc);
 #pragma unroll
         for (int r = 0; r < 16; ++r) h1[r] = fmaxf(acc[r], 0.f);
-        // dout fragment (natural k = co) and the dout tile (rows = co)
-        typename M::Frag fdo = fc_zero_frag<T>();
         f32x16 dtile;
 #pragma unroll
         for (int r = 0; r < 16; ++r) dtile[r] = 0.f;
+        if constexpr (NCO > 0) {
+          // W2^T . dout and the dW2 / db2 partial sums on the VALU (dout is zero where the pixel is out of range)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float t = 0.f;
+#pragma unroll
+            for (int co = 0; co < NCO; ++co) { t += w2r[co][r] * dc[co]; aw2v[co][r] += dc[co] * h1[r]; }
+            acc[r] = t;
+          }
+          if (h == 0) {
+#pragma unroll
+            for (int co = 0; co < NCO; ++co) ab2v[co] += dc[co];
+          }
+        } else {
+        // dout fragment (natural k = co) and the dout tile (rows = co)
+        typename M::Frag fdo = fc_zero_frag<T>();
         if (small_co) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) { M::set(fdo, e, dc[e]); dtile[e] = dc[e]; }      // rows 0..3 (zero on the h == 1 half)
@@ -488,6 +519,7 @@ __global__ __launch_bounds__(256) void fcomb_bwd16_kernel(FcombBwdArgs a, const 
           }
           acc = M::mfma(w2t2, fdo2, acc);
         }
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) d1[r] = (h1[r] > 0.f && valid) ? acc[r] : 0.f;
 #pragma unroll
@@ -498,8 +530,10 @@ __global__ __launch_bounds__(256) void fcomb_bwd16_kernel(FcombBwdArgs a, const 
         for (int r = 0; r < 16; ++r) d0[r] = (h0[r] > 0.f && valid) ? acc[r] : 0.f;
         dfe = M::mfma(w0tp[0], fc_acc_frag<T>(d0, 0), dfe);
         dfe = M::mfma(w0tp[1], fc_acc_frag<T>(d0, 1), dfe);
-        fc_store_tile<T>(tiles + 0 * TS, lp, h, dtile);
-        fc_store_tile<T>(tiles + 1 * TS, lp, h, h1);
+        if constexpr (NCO == 0) {
+          fc_store_tile<T>(tiles + 0 * TS, lp, h, dtile);
+          fc_store_tile<T>(tiles + 1 * TS, lp, h, h1);
+        }
         fc_store_tile<T>(tiles + 2 * TS, lp, h, d1);
         fc_store_tile<T>(tiles + 3 * TS, lp, h, h0);
         fc_store_tile<T>(tiles + 4 * TS, lp, h, d0);
@@ -517,9 +551,11 @@ __global__ __launch_bounds__(256) void fcomb_bwd16_kernel(FcombBwdArgs a, const 
         const int c1 = ((2 * (g & 1) + (p >> 1)) ^ ((r1 >> 2) & 3)) * 8 + 4 * (p & 1);
         const int o0 = r0 * 32 + c0, o1 = r1 * 32 + c1;
         typename M::Frag fl, fr;
-        fl = fc_tr_frag<typename M::Frag>(tiles + 0 * TS + o0, tiles + 0 * TS + o1);     // dout
-        fr = fc_tr_frag<typename M::Frag>(tiles + 1 * TS + o0, tiles + 1 * TS + o1);     // h1
-        aw[2] = M::mfma(fl, fr, aw[2]); as2 = M::mfma(fl, ones, as2);
+        if constexpr (NCO == 0) {
+          fl = fc_tr_frag<typename M::Frag>(tiles + 0 * TS + o0, tiles + 0 * TS + o1);     // dout
+          fr = fc_tr_frag<typename M::Frag>(tiles + 1 * TS + o0, tiles + 1 * TS + o1);     // h1
+          aw[2] = M::mfma(fl, fr, aw[2]); as2 = M::mfma(fl, ones, as2);
+        }
         fl = fc_tr_frag<typename M::Frag>(tiles + 2 * TS + o0, tiles + 2 * TS + o1);     // dh1
         fr = fc_tr_frag<typename M::Frag>(tiles + 3 * TS + o0, tiles + 3 * TS + o1);     // h0
         aw[1] = M::mfma(fl, fr, aw[1]); as1 = M::mfma(fl, ones, as1);
@@ -561,10 +597,27 @@ __global__ __launch_bounds__(256) void fcomb_bwd16_kernel(FcombBwdArgs a, const 
     const int o = fc_row(r, h);
     atomicAdd(a.dw0 + (long)o * WS + j, aw[0][r] * a.inv_scale);
     atomicAdd(a.dw1 + (long)o * 32 + j, aw[1][r] * a.inv_scale);
-    if (o < f.Cout) atomicAdd(a.dw2 + (long)o * 32 + j, aw[2][r] * a.inv_scale);
+    if (NCO == 0 && o < f.Cout) atomicAdd(a.dw2 + (long)o * 32 + j, aw[2][r] * a.inv_scale);
     if (j == 0) {
       atomicAdd(a.db1 + o, as1[r] * a.inv_scale);
-      if (o < f.Cout) atomicAdd(a.db2 + o, as2[r] * a.inv_scale);
+      if (NCO == 0 && o < f.Cout) atomicAdd(a.db2 + o, as2[r] * a.inv_scale);
+    }
+  }
+  if constexpr (NCO > 0) {
+    // per-lane partial sums -> sums over the 32 pixels (lanes j) of each half, then one atomic per (co, channel) and wave
+#pragma unroll
+    for (int co = 0; co < NCO; ++co) {
+#pragma unroll
+      for (int off = 1; off < 32; off <<= 1) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) aw2v[co][r] += __shfl_xor(aw2v[co][r], off);
+        ab2v[co] += __shfl_xor(ab2v[co], off);
+      }
+      if (j == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) atomicAdd(a.dw2 + (long)co * 32 + fc_row(r, h), aw2v[co][r] * a.inv_scale);
+        if (h == 0) atomicAdd(a.db2 + co, ab2v[co] * a.inv_scale);
+      }
     }
   }
 }
@@ -651,14 +704,25 @@ hipError_t launch_fcomb_bwd(const FcombBwdArgs& a, hipStream_t s) {
   }
   if (f.F == 32 && sizeof(T) == 2) {
     if constexpr (sizeof(T) == 2) {
-      static AttrOnce attr16_once;                      // hipFuncSetAttribute is per device
-      if (!attr16_once.cur()) {
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(fcomb_bwd16_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 128 * 32 * 2 + 2 * 256 * 32 * 4);
-        if (e != hipSuccess) return e;
-        attr16_once.cur() = true;
+      static const bool no_compact = getenv("PU_FCOMB_GENERAL") != nullptr;      // diagnostic: the general kernel for every Cout
+      void (*kern)(FcombBwdArgs, const float*, float*) = fcomb_bwd16_kernel<T, 0>;
+      int per_cu = 1;                                   // resident 4-wave blocks per CU by registers
+      if (!no_compact && f.Cout >= 1 && f.Cout <= 4) {
+        per_cu = 2;
+        kern = f.Cout == 1 ? fcomb_bwd16_kernel<T, 1> : f.Cout == 2 ? fcomb_bwd16_kernel<T, 2> : f.Cout == 3 ? fcomb_bwd16_kernel<T, 3> : fcomb_bwd16_kernel<T, 4>;
       }
-      dim3 grid16((unsigned)min((long)24, (HW + 127) / 128), f.B);
-      hipLaunchKernelGGL((fcomb_bwd16_kernel<T>), grid16, dim3(256), 6 * 128 * 32 * 2 + (size_t)2 * f.M * 32 * 4, s, a, zb, dzb);
+      static AttrOnce attr16_once[5];                   // hipFuncSetAttribute is per device (and per kernel)
+      const int ki = per_cu == 2 ? f.Cout : 0;
+      if (!attr16_once[ki].cur()) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 6 * 128 * 32 * 2 + 2 * 256 * 32 * 4);
+        if (e != hipSuccess) return e;
+        attr16_once[ki].cur() = true;
+      }
+      // one resident round: 256 CUs x per_cu blocks shared by the B samples
+      long per_sample = 24;                              // general kernel: three rounds of 256 blocks at B = 32 (round-2 tuning)
+      if (per_cu == 2) { per_sample = 512 / (f.B > 0 ? f.B : 1); if (per_sample < 1) per_sample = 1; }
+      dim3 grid16((unsigned)min(per_sample, (HW + 127) / 128), f.B);
+      hipLaunchKernelGGL(kern, grid16, dim3(256), 6 * 128 * 32 * 2 + (size_t)2 * f.M * 32 * 4, s, a, zb, dzb);
     }
   } else if (f.F == 32) hipLaunchKernelGGL((fcomb_bwd_kernel<T, 32>), grid, dim3(256), lds, s, a, zb, dzb);
   else if (f.F == 16) hipLaunchKernelGGL((fcomb_bwd_kernel<T, 16>), grid, dim3(256), lds, s, a, zb, dzb);

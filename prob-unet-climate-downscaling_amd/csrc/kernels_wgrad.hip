@@ -273,7 +273,7 @@ static hipError_t launch_wg16(const WgradArgs& a, hipStream_t s, WgradReduce* re
   hipLaunchKernelGGL(kern, dim3(split, gy, gz), dim3(64 * NW), lds, s, b);
   if (prof) prof_record(tag, 0, 0, s, false);
   red->slab = a.slab; red->split = split; red->taps = TAPS; red->cout_pad = gy * WBCO; red->cin_pad = gz * BCI; red->Cout = a.Cout; red->Cin = a.Cin;
-  red->dw = a.dw; red->inv_scale = a.inv_scale; red->db0 = a.dbias0; red->db1 = a.dbias1; red->inv_dev = a.inv_scale_dev;
+  red->dw = a.dw; red->inv_scale = a.inv_scale; red->db0 = a.dbias0; red->db1 = a.dbias1; red->inv_dev = a.inv_scale_dev; red->overwrite = a.overwrite;
   return hipGetLastError();
 }
 
@@ -290,7 +290,7 @@ static hipError_t launch_wg16(const WgradArgs& a, hipStream_t s, WgradReduce* re
 template <int TAPS, int L, bool ALLT>
 __global__ __launch_bounds__(256) void wgrad_reduce2_kernel(const float* __restrict__ slab, int split, int cout_pad, int cin_pad, int Cout, int Cin,
                                                              float* __restrict__ dw, float inv_scale, float* db0, float* db1,
-                                                             const float* __restrict__ inv_dev, unsigned nwb, int vec_ok) {
+                                                             const float* __restrict__ inv_dev, unsigned nwb, int vec_ok, int overwrite) {
   constexpr int UB = 256 / L, NT = ALLT ? TAPS : 1;
   __shared__ f32x4 red[NT][256];
   if (inv_dev) inv_scale *= inv_dev[0];            // device-chosen scale of this sub-graph (latent encoders, f16)
@@ -319,8 +319,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce2_kernel(const float* __restr
 #pragma unroll
       for (int j = 0; j < 16; ++j) v += bred[j * 16 + threadIdx.x];
       v *= inv_scale;
-      db0[co] += v;
-      if (db1) db1[co] += v;
+      if (overwrite) { db0[co] = v; if (db1) db1[co] = v; }
+      else { db0[co] += v; if (db1) db1[co] += v; }
     }
     return;
   }
@@ -387,7 +387,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce2_kernel(const float* __restr
     if (vec_ok) {                                  // Cin % 4 == 0 and dw 16-byte aligned: TAPS float4 read-modify-writes of 4 * TAPS consecutive floats
 #pragma unroll
       for (int m = 0; m < TAPS; ++m) {
-        f32x4 o = *reinterpret_cast<f32x4*>(d + 4 * m);
+        f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (!overwrite) o = *reinterpret_cast<f32x4*>(d + 4 * m);
 #pragma unroll
         for (int j = 0; j < 4; ++j) { const int f = 4 * m + j; o[j] += v[f % TAPS][f / TAPS]; }
         *reinterpret_cast<f32x4*>(d + 4 * m) = o;
@@ -397,14 +398,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce2_kernel(const float* __restr
       for (int e4 = 0; e4 < 4; ++e4)
         if (ci + e4 < Cin) {
 #pragma unroll
-          for (int t = 0; t < TAPS; ++t) d[(size_t)e4 * TAPS + t] += v[t][e4];
+          for (int t = 0; t < TAPS; ++t) d[(size_t)e4 * TAPS + t] = (overwrite ? 0.f : d[(size_t)e4 * TAPS + t]) + v[t][e4];
         }
     }
   } else {
     float* d = dw + ((size_t)co * Cin + ci) * TAPS + t0;
 #pragma unroll
     for (int e4 = 0; e4 < 4; ++e4)
-      if (ci + e4 < Cin) d[(size_t)e4 * TAPS] += v[0][e4];
+      if (ci + e4 < Cin) d[(size_t)e4 * TAPS] = (overwrite ? 0.f : d[(size_t)e4 * TAPS]) + v[0][e4];
   }
 }
 
@@ -417,7 +418,7 @@ static void launch_reduce2(const WgradReduce& r, hipStream_t s) {
   const unsigned nbias_blocks = r.db0 ? (unsigned)cdiv(r.Cout, 16) : 0u;
   const int vec_ok = (r.Cin % 4 == 0) && ((reinterpret_cast<uintptr_t>(r.dw) & 15) == 0);
   hipLaunchKernelGGL((wgrad_reduce2_kernel<TAPS, L, ALLT>), dim3(nwb + nbias_blocks), dim3(256), 0, s, r.slab, r.split, r.cout_pad, r.cin_pad,
-                     r.Cout, r.Cin, r.dw, r.inv_scale, r.db0, r.db1, r.inv_dev, nwb, vec_ok);
+                     r.Cout, r.Cin, r.dw, r.inv_scale, r.db0, r.db1, r.inv_dev, nwb, vec_ok, r.overwrite);
 }
 template <int TAPS, bool ALLT>
 static void launch_reduce2_l(const WgradReduce& r, int L, hipStream_t s) {

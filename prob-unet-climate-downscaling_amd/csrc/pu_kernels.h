@@ -5,6 +5,46 @@
 
 namespace pu {
 
+// ---------------------------------------------------------------- GroupNorm work fused into the convolutions (16-bit engines)
+// Where the dropout decisions of a GroupNorm site come from: the counter-hash stream (seed, stream) or an injected keep mask.
+struct DropSrc {
+  float drop_p;                 // 0 = no dropout at this site
+  uint64_t seed; uint32_t stream;
+  const uint8_t* mask;          // optional injected keep mask, dense NHWC uint8 [B,H,W,C] (null: hash stream)
+  int b0;                       // batch offset added to the sample index of the dropout counter
+  const uint8_t* bits;          // optional: the keep decisions the forward saved (GNArgs::keep_bits), one byte per 8 channels
+};
+// keep decisions (bit e = keep) of the 8 consecutive channels starting at dense NHWC index `base` of the site
+__device__ __forceinline__ uint32_t drop_keep_bits8(const uint8_t* mask, uint32_t dkey, uint32_t dthr, uint64_t base) {
+  uint32_t bits = 0;
+  if (mask) {
+    const uint2 m = *reinterpret_cast<const uint2*>(mask + base);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { bits |= ((m.x >> (8 * e)) & 1u) << e; bits |= ((m.y >> (8 * e)) & 1u) << (e + 4); }
+    return bits;
+  }
+#pragma unroll
+  for (int e = 0; e < 8; e += 2) {
+    const uint32_t r = drop_pair(dkey, base + e);
+    bits |= ((r & 0xffffu) < dthr ? 1u : 0u) << e;
+    bits |= ((r >> 16) < dthr ? 1u : 0u) << (e + 1);
+  }
+  return bits;
+}
+// Data-gradient epilogue of the convolution that FOLLOWS a GroupNorm(+scale/shift)+SiLU(+dropout) in the forward: instead of
+// dh = d(loss)/d(GroupNorm output) the kernel stores  dv = dh * keep/(1-p) * silu'(A (x - mean) + Bp)  (the gradient at the
+// pre-activation, rounded to T) and writes per-wave rows of  S1 = sum dv,  S2 = sum dv * (x - mean) * rstd  - pass 1 of the GroupNorm
+// backward (src/networks.py:170-177 differentiated) without its own read of (x, dh) and with the exp / rcp / mask hash evaluated once
+// per element instead of once per pass.  Rows: part[((b * slots + slot) * Cout + c) * 2 + {0, 1}], written, never accumulated.
+struct GNBwdFuse {
+  const void* x; int x_ld;      // GroupNorm input, same geometry as the data gradient being produced; null = off
+  const float* coef;            // [B][C][4] = (A, Bp, group mean, group rstd), the forward's coefficients
+  int C;                        // channels of the GroupNorm (must equal the stored planes of the data gradient)
+  DropSrc drop;
+  float* part; int cap;         // row buffer and its capacity in slots per image
+  int* slots;                   // host pointer: slot count per image of the chosen tiling (0 = not produced: plain dh was stored)
+};
+
 // ---------------------------------------------------------------- convolution
 struct ConvArgs {
   const void* in; int in_ld; int Cin;            // NHWC input view, logical channels
@@ -21,6 +61,7 @@ struct ConvArgs {
   // The launcher reports the slot count per image of the tiling it chose through *stat_slots (host pointer; 0 = this
   // kernel configuration does not produce statistics, the consumer then falls back to its own statistics pass).
   float* stat_out; int stat_cap; int* stat_slots;
+  GNBwdFuse gnb;                                 // optional (data gradient only: no bias / residual / ReLU / accumulate)
 };
 // 16-bit convolutions on >= 16-pixel-wide levels run the cout-split kernel whose weights are packed fragment-major:
 //   [cout tile of 32][32-channel chunk][tap][k-step][lane 0..63][8]  =  W[32 ct + (lane & 31)][tap][32 c + 16 kk + 8 (lane >> 5) + e]
@@ -52,7 +93,7 @@ inline bool conv_uses_mfma16(int elem_size, int taps, int cin_pk, int Cout, int 
   if (mode == 2 && Cout <= 64) return false;
   return mode != 0 && conv_uses_frag_layout(elem_size, H, W) && !conv3_goes_persistent(cin_pk, Cout, H, W);
 }
-struct WgradReduce { const float* slab; int split, taps, cout_pad, cin_pad, Cout, Cin; float* dw; float inv_scale; float* db0; float* db1; const float* inv_dev; };
+struct WgradReduce { const float* slab; int split, taps, cout_pad, cin_pad, Cout, Cin; float* dw; float inv_scale; float* db0; float* db1; const float* inv_dev; int overwrite; };
 struct WgradArgs {
   const void* dy; int dy_ld; int Cout;
   const void* in; int in_ld; int Cin;
@@ -62,6 +103,8 @@ struct WgradArgs {
   float inv_scale;                               // parameter gradients are multiplied by this (loss-scale removal)
   const float* inv_scale_dev;                    // optional device float multiplied on top (sub-graph scale chosen on the device)
   float* dbias0; float* dbias1;                  // optional (16-bit path): bias gradient(s) = column sums of dy, ADDED into
+  int overwrite;                                 // 16-bit path: dw / dbias are WRITTEN instead of added into (the fused ELBO backward, where
+                                                 // every convolution parameter receives exactly one contribution: no memset of the buffer)
 };
 struct PackDesc { long src_off; long dst_off; int Cout, Cin, taps, rows_pk, k_pk, mode; };   // mode: 0 fwd, 1 dgrad; +2 = fragment-major
 
@@ -93,6 +136,9 @@ struct GNArgs {
   int resample;
   float drop_p; uint64_t drop_seed; uint32_t drop_stream;   // drop_p == 0 -> no dropout
   const uint8_t* drop_mask;   // optional injected keep mask, dense NHWC uint8 [B,H,W,C] of this site (null: counter hash)
+  uint8_t* keep_bits;         // optional (16-bit engines, resample == 0): [B,H,W,C/8] bytes, bit e of byte i = keep decision of dense element
+                              // 8 i + e.  The forward apply WRITES them; every backward kernel READS them instead of re-hashing (the mask
+                              // hash was 40 % of the backward kernels' VALU instructions)
   // workspaces (fp32): part [B][nchunk][C][2], stat [B][G][2] (mean, rstd), coef [B][C][4] (A, Bp, mean, rstd; 16-byte aligned)
   float* part; float* stat; float* coef; int nchunk;
   // producer-fused statistics (see ConvArgs::stat_out): channels [0, pc0) from ps0 (ns0 slots per image), the rest from ps1;
@@ -112,6 +158,8 @@ struct GNBwdArgs {
   float* part2;               // [B][nchunk][C][2]
   float inv_scale;            // parameter gradients are multiplied by this
   float* coef2;               // [B][C][3] (P, Q, R)
+  // pass 1 already done by the data-gradient epilogue (GNBwdFuse): `dy` holds dv, rows[b][nrows][C][2] hold its (S1, S2) partials
+  const float* rows; int nrows;
 };
 template <typename T> hipError_t launch_gn_bwd(const GNBwdArgs&, hipStream_t);
 template <typename T> hipError_t launch_gn_apply(const GNArgs&, hipStream_t);                  // apply kernel alone (coefficients in place)
@@ -194,6 +242,8 @@ hipError_t launch_fill(float* p, float v, long n, hipStream_t);
 hipError_t launch_adamw_flat(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps, float wd,
                              float step_size, float inv_bc2_sqrt, hipStream_t, const float* skip_flag = nullptr);
 hipError_t launch_nonfinite_flag(const float* g, long n, float* flag, hipStream_t);
+hipError_t launch_zero_ranges(float* g, const long* ranges_dev, int n, hipStream_t);
+hipError_t launch_scale_grads(float* g, long n, const float* scale_dev, float host_factor, hipStream_t);
 hipError_t launch_adamw_flat_dev(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps, float wd,
                                  float* state, const float* skip_flag, hipStream_t, int phases = 3);   // 1 = advance the counter, 2 = update
 hipError_t launch_mask_to_nhwc_u8(const float* src, uint8_t* dst, int B, int C, long HW, hipStream_t);

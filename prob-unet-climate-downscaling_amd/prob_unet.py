@@ -167,6 +167,7 @@ class _UNetFn(torch.autograd.Function):
                                          "model.prior(x') call with a different x before backward() (one forward in flight per engine)")
         o._gen["grads"] += 1
         lo, hi = o._ranges["unet"]
+        o._unalias_grads(lo, hi)
         o._engine_grads[lo:hi].zero_()
         L.check(L.lib().pu_unet_bwd(o._ctx, L.ptr(dfeat.contiguous().float()), o._stream()), o._ctx, "pu_unet_bwd")
         o._deliver(None, lo, hi)
@@ -191,6 +192,7 @@ class _GaussFn(torch.autograd.Function):
                                          "model.unet(x') call with a different x before backward() (one forward in flight per engine)")
         o._gen["grads"] += 1
         lo, hi = o._ranges[ctx.name]
+        o._unalias_grads(lo, hi)
         o._engine_grads[lo:hi].zero_()
         dmu = torch.zeros_like(o._last_mu[ctx.which]) if dmu is None else dmu.contiguous().float()
         dls = torch.zeros_like(dmu) if dls is None else dls.contiguous().float()
@@ -214,6 +216,7 @@ class _FcombFn(torch.autograd.Function):
         o._check_fresh("fcomb", ctx.gen, "model.fcomb(...)")
         o._gen["grads"] += 1
         lo, hi = o._ranges["fcomb"]
+        o._unalias_grads(lo, hi)
         o._engine_grads[lo:hi].zero_()
         B = dout.shape[0]
         dfeat = torch.empty(ctx.shape, device=dout.device, dtype=torch.float32) if ctx.needs_input_grad[0] else None
@@ -549,33 +552,38 @@ class ProbabilisticUNet(nn.Module):
 
     def _deliver(self, g, lo, hi):
         """Engine gradients [lo, hi) (x grad_output g) -> p.grad (accumulating like autograd does).
-        Under data parallelism the engine gradients are first averaged over the process group (RCCL all-reduce)."""
+        Under data parallelism the engine gradients are first averaged over the process group (RCCL all-reduce).
+        When no parameter of the range has a gradient yet, p.grad becomes a VIEW of the engine's gradient buffer: no copy - the
+        grad_output (a device scalar, 1 for a plain loss.backward()) and the 1 / world of the data-parallel mean are applied in place
+        by one conditional pass that does nothing when the factor is exactly 1 (pu_scale_grads).  The next call that makes the engine
+        rewrite its buffer first moves gradients that are still referenced out of it (`_unalias_grads`)."""
         eg = self._engine_grads[lo:hi]
         P = self._params_in(lo, hi)
-        views = self._grad_views(lo, hi)
-        fresh = all(p.grad is None for p, _, _ in P[:4]) and P[-1][0].grad is None and P[len(P) // 2][0].grad is None
-        fresh = fresh and all(p.grad is None for p, _, _ in P)
+        fresh = all(p.grad is None for p, _, _ in P)
+        host_factor = 1.0
         if self._dp_active:
             from .dp import allreduce_mean_
-            # the 1 / world of the mean rides on the copy below when there is one (saves a pass over the 300 MB buffer)
             if self._dp_works is not None and lo == 0 and hi == self._nparams:
                 self._finish_dp_works()                   # bucketed collectives issued by elbo(): only wait for them here
-                if not fresh:
-                    eg.mul_(1.0 / self._dp_world)
+                host_factor = 1.0 / self._dp_world
             else:
-                allreduce_mean_(eg, self._dp_group, self.dp_bucket_elems, average=not fresh, wire_dtype=self._wire_dtype())
+                allreduce_mean_(eg, self._dp_group, self.dp_bucket_elems, average=False, wire_dtype=self._wire_dtype())
+                host_factor = 1.0 / self._dp_world
             # an overflow on ANY rank makes the SUM non-finite on EVERY rank (inf + x = inf, inf - inf = NaN): the optimizer derives
             # its skip flag from the averaged buffer (FlatAdamW.step), so all ranks skip together without another collective
-            if fresh:
-                g = (g.reshape(()) if g is not None else torch.ones((), device=eg.device)) * (1.0 / self._dp_world)
         if fresh:
-            if g is not None:
-                torch.mul(eg, g.reshape(()), out=self._flat_grad[lo:hi])      # one pass: scale by grad_output while copying
-            else:
-                self._flat_grad[lo:hi].copy_(eg)
-            for (p, off, n), v in zip(P, views):
+            gs = g.reshape(()).float().contiguous() if g is not None else None
+            if gs is not None or host_factor != 1.0:
+                if eg.data_ptr() % 16 == 0:
+                    L.check(L.lib().pu_scale_grads(L.ptr(eg), hi - lo, L.ptr(gs), float(host_factor), self._stream()), self._ctx, "pu_scale_grads")
+                else:                                     # a sub-module range that does not start on a 16-byte boundary
+                    eg.mul_(gs * host_factor if gs is not None else host_factor)
+            for (p, off, n), v in zip(P, self._grad_views(lo, hi, self._engine_grads)):
                 p.grad = v
+            self._grads_aliased = True
         else:
+            if host_factor != 1.0:
+                eg = eg * host_factor
             if g is not None:
                 eg = eg * g.reshape(())
             for p, off, n in P:
@@ -584,6 +592,28 @@ class ProbabilisticUNet(nn.Module):
                     p.grad = ge.clone()
                 else:
                     p.grad.add_(ge)
+
+    def _unalias_grads(self, lo=0, hi=None):
+        """Called before the engine rewrites its gradient buffer in [lo, hi): parameters whose .grad still is a view of that buffer
+        (no zero_grad() since the last backward - gradient accumulation) get their gradient moved to the stable flat buffer."""
+        if not getattr(self, "_grads_aliased", False) or self._engine_grads is None:
+            return
+        hi = self._nparams if hi is None else hi
+        base = self._engine_grads.data_ptr()
+        P = self._params_in(lo, hi)
+        views = None
+        moved = False
+        for i, (p, off, n) in enumerate(P):
+            gr = p.grad
+            if gr is not None and gr.data_ptr() == base + 4 * off:
+                if views is None:
+                    views = self._grad_views(lo, hi, self._flat_grad)
+                if not moved:
+                    self._flat_grad[lo:hi].copy_(self._engine_grads[lo:hi])      # one pass; ranges without a live view are harmless
+                    moved = True
+                p.grad = views[i]
+        if lo == 0 and hi == self._nparams:
+            self._grads_aliased = False
 
     def _start_bucket_allreduce(self):
         """Issue one all-reduce (SUM) per gradient bucket of the fused backward on a side stream that waits for the bucket's
@@ -638,11 +668,12 @@ class ProbabilisticUNet(nn.Module):
             return torch.bfloat16
         raise ValueError(f"dp_wire_dtype must be None or 'bf16', got {self.dp_wire_dtype!r}")
 
-    def _grad_views(self, lo, hi):
-        key = ("gv", lo, hi, self._flat_grad.data_ptr())
+    def _grad_views(self, lo, hi, buf=None):
+        buf = self._flat_grad if buf is None else buf
+        key = ("gv", lo, hi, buf.data_ptr())
         cache = self.__dict__.setdefault("_pin_cache", {})
         if key not in cache:
-            cache[key] = [self._flat_grad[off:off + n].view(p.shape) for p, off, n in self._params_in(lo, hi)]
+            cache[key] = [buf[off:off + n].view(p.shape) for p, off, n in self._params_in(lo, hi)]
         return cache[key]
 
     def _params_in(self, lo, hi):
@@ -851,6 +882,7 @@ class ProbabilisticUNet(nn.Module):
         if with_bwd:
             self._gen["grads"] += 1
             self._finish_dp_works()                       # a previous elbo()'s collectives still own the gradient buffer
+            self._unalias_grads()                         # gradients still referenced (accumulation) leave the engine's buffer first
         L.check(L.lib().pu_elbo_fwd_bwd(self._ctx, L.ptr(x), L.ptr(target), L.ptr(eps), B, Mx, kind,
                                         float(self.beta_0), float(self.beta_1), float(self.beta_2), float(alpha), train,
                                         self._next_seed(), with_bwd, L.ptr(scal), L.ptr(klv), L.ptr(kl2v), self._stream()),
@@ -1096,17 +1128,23 @@ class FlatAdamW:
         if self.exp_avg is None or self.exp_avg.device != dev:
             self.exp_avg = torch.zeros_like(m._flat); self.exp_avg_sq = torch.zeros_like(m._flat)
             self._state = torch.zeros(4, device=dev, dtype=torch.float32); self._flag = torch.zeros(1, device=dev, dtype=torch.float32)
-        # bring the flat gradient buffer in line with what p.grad says: views of it stay, foreign tensors are copied in;
-        # parameters whose .grad is None are left out of the update altogether (torch.optim skips them: no decay, no moment
-        # update) - their range of the flat buffer may still hold an earlier step's values and is never read
-        base = m._flat_grad.data_ptr()
+        # which buffer do the gradients live in?  Views of the engine's gradient buffer (the usual case: elbo() -> backward() with no
+        # accumulation, see ProbabilisticUNet._deliver) are read in place; otherwise the stable flat buffer is brought in line with what
+        # p.grad says: views of it stay, foreign tensors are copied in.  Parameters whose .grad is None are left out of the update
+        # altogether (torch.optim skips them: no decay, no moment update) - their range may hold stale values and is never read
+        P = m._params_in(0, m._nparams)
+        ebase = m._engine_grads.data_ptr()
+        have = [(p, off, n) for p, off, n in P if p.grad is not None]
+        if have and all(p.grad.data_ptr() == ebase + 4 * off and p.grad.dtype == torch.float32 for p, off, n in have):
+            gbuf = m._engine_grads
+        else:
+            gbuf = m._flat_grad
+        base = gbuf.data_ptr()
         runs = []                         # contiguous [lo, hi) runs of parameters that have a gradient
-        for p, off, n in m._params_in(0, m._nparams):
+        for p, off, n in have:
             g = p.grad
-            if g is None:
-                continue
             if g.data_ptr() != base + 4 * off or g.dtype != torch.float32:
-                m._flat_grad[off:off + n].copy_(g.reshape(-1))
+                gbuf[off:off + n].copy_(g.reshape(-1))
             if runs and runs[-1][1] == off:
                 runs[-1][1] = off + n
             else:
@@ -1124,12 +1162,12 @@ class FlatAdamW:
             flag = L.ptr(self._flag)
         hyper = (float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.weight_decay))
         if len(runs) == 1 and runs[0] == [0, m._nparams]:
-            L.check(lib.pu_adamw_step_dev(L.ptr(m._flat), L.ptr(m._flat_grad), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq), m._nparams,
+            L.check(lib.pu_adamw_step_dev(L.ptr(m._flat), L.ptr(gbuf), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq), m._nparams,
                                           *hyper, L.ptr(self._state), flag, m._stream()), m._ctx, "pu_adamw_step_dev")
         else:
             L.check(lib.pu_adamw_prepare(L.ptr(self._state), flag, hyper[0], hyper[1], hyper[2], m._stream()), m._ctx, "pu_adamw_prepare")
             for lo, hi in runs:
                 at = lambda t: C.c_void_p(t.data_ptr() + 4 * lo)
-                L.check(lib.pu_adamw_apply(at(m._flat), at(m._flat_grad), at(self.exp_avg), at(self.exp_avg_sq), hi - lo, *hyper,
+                L.check(lib.pu_adamw_apply(at(m._flat), at(gbuf), at(self.exp_avg), at(self.exp_avg_sq), hi - lo, *hyper,
                                            L.ptr(self._state), m._stream()), m._ctx, "pu_adamw_apply")
         m._params_dirty()

@@ -127,6 +127,10 @@ def test_bench_self_launch_two_rank_rehearsal():
     assert out["n_gpus"] == 2 and out["config"]["world_size_seen_by_backend"] == 2 and out["config"]["backend"] == "gloo"
     assert out["config"]["dp_gradient_buckets"] >= 2 and out["config"]["loss_finite"] is True
     assert out["value"] > 0 and out["scaling"] == "weak" and out["config"]["global_batch"] == 4
+    d = out["dp_diagnostics"]                                       # what makes the first real multi-GPU run diagnosable
+    assert len(d["per_rank_ms_per_step"]) == 2 and all(v > 0 for v in d["per_rank_ms_per_step"])
+    for k in ("ms_per_step_buckets_4", "ms_per_step_buckets_0", "ms_per_step_no_allreduce", "exposed_comm_ms_buckets_4", "exposed_comm_ms_buckets_0"):
+        assert k in d, (k, d)
 
 
 def test_bench_single_rank_rccl_path():
@@ -145,6 +149,7 @@ def test_bench_single_rank_rccl_path():
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert out["config"]["backend"] == "nccl" and out["config"]["world_size_seen_by_backend"] == 1
     assert out["config"]["dp_gradient_buckets"] >= 2 and out["config"]["loss_finite"] is True and out["value"] > 0
+    assert out["dp_diagnostics"]["ms_per_step_no_allreduce"] > 0 and len(out["dp_diagnostics"]["per_rank_ms_per_step"]) == 1
 
 
 def _worker_wmse(rank, world, initfile, outdir):
