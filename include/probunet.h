@@ -25,6 +25,7 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#pragma GCC visibility push(default)   /* the library is built with -fvisibility=hidden: only this C ABI is exported */
 
 typedef struct pu_ctx pu_ctx;
 
@@ -241,6 +242,7 @@ int pu_profile_collect(pu_prof_entry* out, int max_entries);
 /* The single-op test hooks and the convolution micro-benchmark (pu_op_*, pu_bench_conv) are NOT part of this ABI: they are
  * declared in include/probunet_testing.h. */
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

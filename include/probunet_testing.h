@@ -11,6 +11,7 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#pragma GCC visibility push(default)   /* the library is built with -fvisibility=hidden: only this C ABI is exported */
 
 /* ---- single-op entry points (used by tests/ to pin each kernel against a torch fp32 reference) ----------- */
 /* 3x3 (ks=3) or 1x1 (ks=1) convolution on NCHW fp32 tensors through the engine's NHWC implicit-GEMM kernels in
@@ -38,6 +39,7 @@ int pu_op_gnsilu(int dtype, int resample, int B, int C, int H, int W, const floa
 int pu_op_wmse_msssim(const float* pred, const float* target, int B, int M, int C, int H, int W, float alpha_w, float beta_w,
                       float lam_w, float data_range, float gscale, float* out_scalars, float* dpred, void* stream);
 
+#pragma GCC visibility pop
 #ifdef __cplusplus
 }
 #endif

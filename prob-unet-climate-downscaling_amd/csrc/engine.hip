@@ -82,7 +82,7 @@ struct pu_ctx {
   float* wg_slab = nullptr; long wg_slab_floats = 0;
   float* gn_part = nullptr; float* gn_part2 = nullptr; float* gn_coef2 = nullptr; float* bias_part = nullptr; TV dv_scratch;
   float* gn_rows = nullptr; size_t gn_rows_per_img = 0; int gn_rows_cap = 0;   // pass-1 rows written by data-gradient epilogues: [B][slots][C][2]
-  long fuse_bwd_minhw = 128L * 128;     // GroupNorm sites with at least this many pixels use the fused backward (PU_GN_FUSE_BWD_MINHW; 0 = off)
+  long fuse_bwd_minhw = 256L * 256;     // GroupNorm sites with at least this many pixels use the fused backward (PU_GN_FUSE_BWD_MINHW; 0 = off)
   float *z = nullptr, *dz = nullptr, *preds = nullptr, *dpreds = nullptr, *kl = nullptr, *kl2 = nullptr, *scal = nullptr;
   Act fc_feat;                      // standalone fcomb input (converted) + its gradient
   float* fc_z = nullptr; int fc_B = 0; int fc_bcast = 0;

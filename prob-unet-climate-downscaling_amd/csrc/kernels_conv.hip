@@ -106,18 +106,6 @@ constexpr int KC = 32;     // channels staged per K chunk
 // dummy address and zeroed by a select - a select next to the load makes the wave wait for the load at once (see conv3_kernel)
 __device__ __attribute__((aligned(16))) unsigned int g_zero16[4] = {0u, 0u, 0u, 0u};
 
-// Diagnostic builds only (tools/ablate_conv.sh compiles extra copies of the library with -DPU_ABLATE=<bits>; results are wrong by
-// design, only the timing is read): 1 = weight fragments always from chunk 0 of tile 0 (L1/L2-hot), 2 = halo tile staged once,
-// 4 = no block barriers in the chunk loop, 8 = no LDS fragment reads, 16 = no output stores.  Production: 0.
-#ifndef PU_ABLATE
-#define PU_ABLATE 0
-#endif
-// Experimental variant of conv3_kernel (A/B builds through tools/ablate_conv.sh with VARIANT=<bits>): 2 = the two co-resident blocks
-// of a CU alternate s_setprio per chunk (fair MFMA arbitration; measured: no gain).  (1 = LDS fragment reads two groups ahead: no gain, removed.)
-#ifndef PU_VARIANT
-#define PU_VARIANT 0
-#endif
-
 // ------------------------------------------------------------------ forward / dgrad implicit GEMM
 // Block = 64*WM*WN threads; pixel tile TH x TW (BM = TH*TW pixels, BM/WM per wave in 32-pixel MFMA columns);
 // cout tile BN = 32*NTN*WN.  K loop over 32-channel chunks: the global loads of chunk c+1 are issued into registers
@@ -313,14 +301,25 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(ConvArgs a) {
   }
 }
 
-// Fused GroupNorm statistics: lane l owns the 8-channel chunk (l & 3) of every pixel it stores; after a butterfly over the
+// Sum over the 16 lanes of equal (lane & 3), delivered to every lane, without LDS traffic: two DPP row rotations inside each
+// 16-lane row, then v_permlane16_swap / v_permlane32_swap across the rows.  (The ds_bpermute butterfly this replaces cost 64 LDS
+// crossbar round trips per wave and tile.)  Inline asm: __builtin_amdgcn_permlane16/32_swap miscompiles on ROCm 7.2 when both
+// results are used (the sum came out as vdst + vdst; scratch/t_dpp.hip is the probe), and the swap needs two wait states after a
+// VALU write of its operands (s_nop 1).
+__device__ __forceinline__ float wave_sum_mod4(float x) {
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x124, 0xf, 0xf, false));   // row_ror:4
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x128, 0xf, 0xf, false));   // row_ror:8
+  float p = x, q = x;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(p), "+v"(q));
+  x = p + q; p = x; q = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(p), "+v"(q));
+  return p + q;
+}
+// Fused GroupNorm statistics: lane l owns the 8-channel chunk (l & 3) of every pixel it stores; after the reduction over the
 // 16 lanes of equal chunk, lanes 0..3 hold the wave's (sum, sum of squares) per channel and write one 64-byte row each.
 __device__ __forceinline__ void wave_stat_store(float* s1, float* s2, int l, float* dst, bool ok) {
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-#pragma unroll
-    for (int off = 4; off < 64; off <<= 1) { s1[e] += __shfl_xor(s1[e], off); s2[e] += __shfl_xor(s2[e], off); }
-  }
+  for (int e = 0; e < 8; ++e) { s1[e] = wave_sum_mod4(s1[e]); s2[e] = wave_sum_mod4(s2[e]); }
   if (l < 4 && ok) {
 #pragma unroll
     for (int e = 0; e < 8; e += 2) {
@@ -351,9 +350,21 @@ static inline void gnb_resolve(ConvArgs& a, int slots) {
 // (ERS-element rows); each lane takes (pixel, 8-cout chunk) vectors: residual / accumulate / ReLU in the 16-byte domain, 64-byte
 // coalesced runs per pixel, plus either the GroupNorm statistics of the stored values (forward producers) or, for a data gradient that
 // feeds a GroupNorm backward (a.gnb), the pre-activation gradient dv and its pass-1 rows (see GNBwdFuse).
+// Addressing: pixbase = index of the tile's first pixel ((b * H + ty0) * W + tx0), lpix[it] = the lane's pixel offset inside the tile
+// for vector `it` ((m / TW) * W + m % TW, tile-invariant: the persistent kernel computes it once), everything in 32-bit element
+// offsets (pu_create rejects plans whose tensors reach 2^32 elements) - the 64-bit multiplies of the first form were a measurable
+// part of an instruction-bound kernel (conv3p issues ~600 non-MFMA instructions per 36 MFMAs).
+template <int NTM, int TW>
+__device__ __forceinline__ void conv3_epilogue_lanes(int l, int wm, int W, unsigned* lpix) {
+#pragma unroll
+  for (int it = 0; it < NTM * 2; ++it) {
+    const int m = wm * NTM * 32 + ((it * 64 + l) >> 2);
+    lpix[it] = (unsigned)((m / TW) * W + (m % TW));
+  }
+}
 template <typename T, int NTM, int TW, int TH, int WM, bool GNB>
-__device__ __forceinline__ void conv3_epilogue_store(const ConvArgs& a, const T* stage, int l, int wm, int ct, int b, int ty0, int tx0,
-                                                     int tiles_x, int tiles_y) {
+__device__ __forceinline__ void conv3_epilogue_store(const ConvArgs& a, const T* stage, int l, int wm, int ct, int b, unsigned pixbase,
+                                                     int tile_xy, int tiles_per_img, const unsigned* lpix) {
   constexpr int ERS = 40;
   constexpr int NIT = NTM * 2;
   T* out = reinterpret_cast<T*>(a.out);
@@ -363,20 +374,16 @@ __device__ __forceinline__ void conv3_epilogue_store(const ConvArgs& a, const T*
   for (int e = 0; e < 8; ++e) { s1[e] = 0.f; s2[e] = 0.f; }
   const int ch = l & 3;
   const int co = ct * 32 + ch * 8;
-  const int slots = tiles_x * tiles_y * WM;
-  const int slot = ((ty0 / TH) * tiles_x + tx0 / TW) * WM + wm;
+  const int slots = tiles_per_img * WM;
+  const int slot = tile_xy * WM + wm;
+  const bool okc = co < a.Cout;
   if constexpr (GNB) {
     // ---- data gradient -> dv of the preceding GroupNorm + SiLU (+ dropout), pass-1 rows
     const T* gx = reinterpret_cast<const T*>(a.gnb.x);
-    const bool okc = co < a.Cout;
     V16 xr[NIT];
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {                          // every x vector in flight before the first use
-      const int pw = (it * 64 + l) >> 2;
-      const int m = wm * NTM * 32 + pw;
-      const size_t pix = (size_t)(b * a.H + ty0 + m / TW) * a.W + tx0 + m % TW;
-      xr[it] = *reinterpret_cast<const V16*>(gx + pix * a.gnb.x_ld + (okc ? co : 0));
-    }
+    for (int it = 0; it < NIT; ++it)                             // every x vector in flight before the first use
+      xr[it] = *reinterpret_cast<const V16*>(gx + (size_t)((pixbase + lpix[it]) * (unsigned)a.gnb.x_ld + (okc ? co : 0)));
     float cA[8], cB[8], cM[8];
     const float4* cf = reinterpret_cast<const float4*>(a.gnb.coef) + ((size_t)b * a.Cout + (okc ? co : 0));
 #pragma unroll
@@ -392,8 +399,7 @@ __device__ __forceinline__ void conv3_epilogue_store(const ConvArgs& a, const T*
     if (dp > 0.f && okc) {
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
-        const int m = wm * NTM * 32 + ((it * 64 + l) >> 2);
-        const uint64_t base = ((uint64_t)(b + a.gnb.drop.b0) * HW + (uint64_t)(ty0 + m / TW) * a.W + (tx0 + m % TW)) * (uint64_t)a.Cout + (uint64_t)co;
+        const uint64_t base = ((uint64_t)a.gnb.drop.b0 * HW + (uint64_t)(pixbase + lpix[it])) * (uint64_t)a.Cout + (uint64_t)co;
         kbs[it] = a.gnb.drop.bits ? (uint32_t)a.gnb.drop.bits[base >> 3] : drop_keep_bits8(a.gnb.drop.mask, dkey, dthr, base);
       }
     }
@@ -401,8 +407,6 @@ __device__ __forceinline__ void conv3_epilogue_store(const ConvArgs& a, const T*
 #pragma unroll
       for (int it = 0; it < NIT; ++it) {
         const int pw = (it * 64 + l) >> 2;
-        const int m = wm * NTM * 32 + pw;
-        const size_t pix = (size_t)(b * a.H + ty0 + m / TW) * a.W + tx0 + m % TW;
         float v[8], xv[8];
         unpack<T>(*reinterpret_cast<const V16*>(stage + pw * ERS + ch * 8), v);
         unpack<T>(xr[it], xv);
@@ -415,7 +419,7 @@ __device__ __forceinline__ void conv3_epilogue_store(const ConvArgs& a, const T*
           v[e] = dh * dsilu_f<false>(cA[e] * d[e] + cB[e]);
         }
         const V16 pk = pack<T>(v);
-        *reinterpret_cast<V16*>(out + pix * a.out_ld + co) = pk;
+        *reinterpret_cast<V16*>(out + (size_t)((pixbase + lpix[it]) * (unsigned)a.out_ld + co)) = pk;
         float w[8]; unpack<T>(pk, w);                            // sums of the values as stored (what pass 2 reads)
 #pragma unroll
         for (int e = 0; e < 8; ++e) { s1[e] += w[e]; s2[e] += w[e] * d[e]; }
@@ -426,40 +430,43 @@ __device__ __forceinline__ void conv3_epilogue_store(const ConvArgs& a, const T*
     wave_stat_store(s1, s2, l, a.gnb.part + (((size_t)b * slots + slot) * a.Cout + co) * 2, okc);
     return;
   }
+  const bool mod = res != nullptr || a.accumulate || a.relu;      // (wave-uniform)
+  if (okc) {
 #pragma unroll
-  for (int it = 0; it < NIT; ++it) {
-    const int i = it * 64 + l;                               // (pixel of the wave, 8-cout chunk)
-    const int pw = i >> 2;
-    const int m = wm * NTM * 32 + pw;
-    const int gy = ty0 + m / TW, gx = tx0 + m % TW;
-    const size_t pix = (size_t)(b * a.H + gy) * a.W + gx;
-    if (co < a.Cout) {
+    for (int it = 0; it < NIT; ++it) {
+      const int pw = (it * 64 + l) >> 2;                          // (pixel of the wave, 8-cout chunk ch)
+      const unsigned pix = pixbase + lpix[it];
+      T* op = out + (size_t)(pix * (unsigned)a.out_ld + co);
+      const V16 raw = *reinterpret_cast<const V16*>(stage + pw * ERS + ch * 8);
       float v[8];
-      unpack<T>(*reinterpret_cast<const V16*>(stage + pw * ERS + ch * 8), v);
-      if (res) {
-        float r[8]; unpack<T>(*reinterpret_cast<const V16*>(res + pix * a.res_ld + co), r);
+      unpack<T>(raw, v);
+      V16 pk = raw;
+      if (mod) {
+        if (res) {
+          float r[8]; unpack<T>(*reinterpret_cast<const V16*>(res + (size_t)(pix * (unsigned)a.res_ld + co)), r);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += r[e];
+          for (int e = 0; e < 8; ++e) v[e] += r[e];
+        }
+        if (a.accumulate) {
+          float r[8]; unpack<T>(*reinterpret_cast<const V16*>(op), r);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += r[e];
+        }
+        if (a.relu) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+        }
+        pk = pack<T>(v);
+        if (a.stat_out) unpack<T>(pk, v);                         // statistics of the values as stored (rounded to T)
       }
-      if (a.accumulate) {
-        float r[8]; unpack<T>(*reinterpret_cast<const V16*>(out + pix * a.out_ld + co), r);
+      *reinterpret_cast<V16*>(op) = pk;
+      if (a.stat_out) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += r[e];
-      }
-      if (a.relu) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
-      }
-      const V16 pk = pack<T>(v);
-      if (!(PU_ABLATE & 16) || pk.w[0] == 0x12345678u) *reinterpret_cast<V16*>(out + pix * a.out_ld + co) = pk;
-      if (a.stat_out) {                                      // statistics of the values as stored (rounded to T)
-        float w[8]; unpack<T>(pk, w);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { s1[e] += w[e]; s2[e] += w[e] * w[e]; }
+        for (int e = 0; e < 8; ++e) { s1[e] += v[e]; s2[e] += v[e] * v[e]; }
       }
     }
   }
-  if (a.stat_out) wave_stat_store(s1, s2, l, a.stat_out + (((size_t)b * slots + slot) * a.Cout + co) * 2, co < a.Cout);
+  if (a.stat_out) wave_stat_store(s1, s2, l, a.stat_out + (((size_t)b * slots + slot) * a.Cout + co) * 2, okc);
 }
 
 // ------------------------------------------------------------------ conv3: cout-split waves, weights straight to registers
@@ -494,10 +501,6 @@ __global__ __launch_bounds__(64 * WM * WN, (MS == 16 && TH * TW / WM <= 128) ? 2
   const int tid = threadIdx.x, l = tid & 63, wave = tid >> 6;
   const int wm = wave % WM, wn = wave / WM;
   const int tiles_x = a.W / TW, tiles_y = a.H / TH;
-#if PU_ABLATE & 32
-  const uint64_t ts0 = __builtin_amdgcn_s_memtime(), tr0 = __builtin_amdgcn_s_memrealtime();
-  uint64_t ts1 = 0, ts2 = 0;
-#endif
   int pt = blockIdx.x;
   if ((gridDim.x & 7) == 0) pt = (pt & 7) * (gridDim.x >> 3) + (pt >> 3);   // XCD-aware: each XCD (L2) gets a contiguous band of
                                                                              // pixel tiles, so halo rows are re-read from its own L2
@@ -560,8 +563,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MS == 16 && TH * TW / WM <= 128) ? 2
   const T* wbase = have_w ? wfrag : reinterpret_cast<const T*>(a.wpk) + l * 8;     // idle waves read tile 0 (never stored)
   auto wload = [&](int c, int t, int kk) -> typename M::Frag {
     union { V16 v; typename M::Frag f; } u;
-    if (PU_ABLATE & 1) c = 0;
-    u.v = *reinterpret_cast<const V16*>(((PU_ABLATE & 1) ? reinterpret_cast<const T*>(a.wpk) + l * 8 : wbase) + ((size_t)(c * TAPS + t) * 2 + kk) * 512);
+    u.v = *reinterpret_cast<const V16*>(wbase + ((size_t)(c * TAPS + t) * 2 + kk) * 512);
     return u.f;
   };
   int pbase[MS == 32 ? NTM : NPG];
@@ -590,22 +592,11 @@ __global__ __launch_bounds__(64 * WM * WN, (MS == 16 && TH * TW / WM <= 128) ? 2
   }
   lstore(0, 0);
   __syncthreads();
-#if PU_ABLATE & 32
-  ts1 = __builtin_amdgcn_s_memtime();
-#endif
-#if PU_VARIANT & 2
-  // the block that was dispatched second onto this CU has a non-zero LDS base: it is the younger wave on every SIMD and loses the
-  // age-ordered MFMA arbitration; the two blocks take turns at priority 1, one chunk each
-  const int young = (__builtin_amdgcn_s_getreg((7 << 11) | (0 << 6) | 6) & 0xff) != 0 ? 1 : 0;
-#endif
   int cur = 0;
   for (int c = 0; c < nch; ++c) {
-#if PU_VARIANT & 2
-    if ((c ^ young) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
-#endif
     const bool more = c + 1 < nch;
     const int cn = more ? c + 1 : c;               // the last chunk harmlessly re-reads its own fragments
-    if (!(PU_ABLATE & 2)) gload(cn * KC);          // unconditional (the last chunk re-reads itself): the chunk body stays ONE basic
+    gload(cn * KC);                                // unconditional (the last chunk re-reads itself): the chunk body stays ONE basic
                                                    // block, so the compiler's s_waitcnt vmcnt counts are exact across the back-edge
     const T* sb = sIn + cur * BUF;
     // software-pipelined over the 2*TAPS (tap, k-step) groups: the NTM LDS fragment reads of group g+1 are issued between
@@ -637,10 +628,6 @@ __global__ __launch_bounds__(64 * WM * WN, (MS == 16 && TH * TW / WM <= 128) ? 2
     typename M::Frag fb[2][NTM];
 #pragma unroll
     for (int j = 0; j < NTM; ++j) fb[0][j] = *reinterpret_cast<const typename M::Frag*>(sb + pbase[j]);
-    if (PU_ABLATE & 8) {
-#pragma unroll
-      for (int j = 0; j < NTM; ++j) fb[1][j] = fb[0][j];
-    }
 #pragma unroll
     for (int g = 0; g < 2 * TAPS; ++g) {
       const int t = g >> 1, kk = g & 1;
@@ -648,7 +635,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MS == 16 && TH * TW / WM <= 128) ? 2
         const int t1 = (g + 1) >> 1, kk1 = (g + 1) & 1;
         const int toff1 = ((t1 / KS) * IW + (t1 % KS)) * KCP + kk1 * 16;
 #pragma unroll
-        for (int j = 0; j < NTM; ++j) if (!(PU_ABLATE & 8)) fb[(g + 1) & 1][j] = *reinterpret_cast<const typename M::Frag*>(sb + pbase[j] + toff1);
+        for (int j = 0; j < NTM; ++j) fb[(g + 1) & 1][j] = *reinterpret_cast<const typename M::Frag*>(sb + pbase[j] + toff1);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -658,14 +645,10 @@ __global__ __launch_bounds__(64 * WM * WN, (MS == 16 && TH * TW / WM <= 128) ? 2
                                                    // under the 8 MFMAs instead of being sunk next to their consumers
     }
     }
-    if (more && !(PU_ABLATE & 2)) lstore(cur ^ 1, (c + 1) * KC);
-    if (!(PU_ABLATE & 4)) __syncthreads();
-    if (!(PU_ABLATE & 2)) cur ^= 1;
+    if (more) lstore(cur ^ 1, (c + 1) * KC);
+    __syncthreads();
+    cur ^= 1;
   }
-  if (PU_ABLATE & 4) __syncthreads();
-#if PU_ABLATE & 32
-  ts2 = __builtin_amdgcn_s_memtime();
-#endif
 
   // ---- epilogue: D[row = cout][col = pixel] -> (+bias) -> wave-private LDS tile [pixel][32 couts] (80-byte rows) ->
   //      16-byte rows per lane: residual / accumulate / ReLU in the 16-byte domain, fully coalesced 64-byte runs per pixel
@@ -704,19 +687,10 @@ __global__ __launch_bounds__(64 * WM * WN, (MS == 16 && TH * TW / WM <= 128) ? 2
       }
     }
   }
-  conv3_epilogue_store<T, NTM, TW, TH, WM, GNB>(a, stage, l, wm, ct, b, ty0, tx0, tiles_x, tiles_y);
-#if PU_ABLATE & 32
-  {
-    const uint64_t ts3 = __builtin_amdgcn_s_memtime(), tr3 = __builtin_amdgcn_s_memrealtime();
-    const unsigned hwid = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4), xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);
-    if (l == 0 && wave == 0 && (((blockIdx.x + 7 * blockIdx.y) % 13) == 0))
-      printf("blk %4d,%d xcc %u se %u cu %2u simd %u | start %8llu end %8llu (x10ns) | prologue %6llu loop %7llu (%5llu/chunk) epilogue %6llu cyc | %.3f GHz\n",
-             (int)blockIdx.x, (int)blockIdx.y, xcc & 15u, (hwid >> 13) & 7u, (hwid >> 8) & 15u, (hwid >> 4) & 3u,
-             (unsigned long long)(tr0 % 100000000ull), (unsigned long long)(tr3 % 100000000ull),
-             (unsigned long long)(ts1 - ts0), (unsigned long long)(ts2 - ts1), (unsigned long long)((ts2 - ts1) / nch), (unsigned long long)(ts3 - ts2),
-             (double)(ts3 - ts0) / (double)(tr3 - tr0) * 0.1);
-  }
-#endif
+  unsigned lpix[NTM * 2];
+  conv3_epilogue_lanes<NTM, TW>(l, wm, a.W, lpix);
+  conv3_epilogue_store<T, NTM, TW, TH, WM, GNB>(a, stage, l, wm, ct, b, (unsigned)((b * a.H + ty0) * a.W + tx0), (ty0 / TH) * tiles_x + tx0 / TW,
+                                                tiles_x * tiles_y, lpix);
 }
 
 // ------------------------------------------------------------------ conv3p: persistent variant for K <= 64 input channels
@@ -725,8 +699,10 @@ __global__ __launch_bounds__(64 * WM * WN, (MS == 16 && TH * TW / WM <= 128) ? 2
 // fragments in registers (NCH x taps x 2 fragments, loaded once), walks over many pixel tiles, and software-pipelines them:
 // the halo tile of tile t+1 is in flight (global -> registers) during the MFMAs of tile t and lands in the other LDS buffer
 // afterwards; the epilogue stores of tile t drain under the MFMAs of tile t+1.  One barrier per tile.
-template <typename T, int KS, int TH, int TW, int WM, int WN, int NCH, bool GNB = false>
-__global__ __launch_bounds__(64 * WM * WN, (GNB && NCH == 1 && WN == 1) ? 2 : 1) void conv3p_kernel(ConvArgs a) {
+// PF = tiles whose halo loads are kept in flight per block (register sets): 1, or 2 (the 32 -> 32 configuration, whose two resident blocks per
+// CU otherwise keep only ~43 KB of loads in flight per CU - below what hides the loaded HBM latency at 6 TB/s)
+template <typename T, int KS, int TH, int TW, int WM, int WN, int NCH, bool GNB = false, int PF = 1>
+__global__ __launch_bounds__(64 * WM * WN, ((GNB || PF == 2) && NCH == 1 && WN == 1) ? 2 : 1) void conv3p_kernel(ConvArgs a) {
   typedef MM<T> M;
   constexpr int NT = 64 * WM * WN;
   constexpr int BM = TH * TW;
@@ -779,32 +755,45 @@ __global__ __launch_bounds__(64 * WM * WN, (GNB && NCH == 1 && WN == 1) ? 2 : 1)
     pbase[j] = ((m / TW) * IW + (m % TW)) * KCP + 8 * (l >> 5);
   }
 
-  V16 ri[NCH][NVI];
+  V16 ri[NCH][NVI], rj[PF == 2 ? NCH : 1][PF == 2 ? NVI : 1];
   const ptrdiff_t zoff = reinterpret_cast<const T*>(g_zero16) - in;
-  auto gload = [&](int tile) {
+  // tile-invariant staging plan of this thread: element offset of halo vector k relative to the tile's first pixel, and which
+  // image edges it lies beyond when the tile touches them (bit 0 top, 1 bottom, 2 left, 3 right; bit 4 = slot unused)
+  int hoff[NVI]; unsigned hedge = 0;
+#pragma unroll
+  for (int k = 0; k < NVI; ++k) {
+    const int i = tid + k * NT;
+    const int ii = i < NVI_TOT ? i : 0;
+    const int pix = ii / CV, cv = ii - pix * CV;
+    const int hy = pix / IW, hx = pix - hy * IW;
+    hoff[k] = ((hy - PADP) * a.W + (hx - PADP)) * a.in_ld + cv * 8;
+    unsigned e = (hy < PADP ? 1u : 0u) | (hy >= TH + PADP ? 2u : 0u) | (hx < PADP ? 4u : 0u) | (hx >= TW + PADP ? 8u : 0u) | (i < NVI_TOT ? 0u : 16u);
+    hedge |= e << (5 * k);
+  }
+  static_assert(NVI * 5 <= 32, "edge bits of the staging plan");
+  bool chan_ok[NCH];
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) chan_ok[c] = c * KC + ((tid % CV) * 8) < a.Cin;      // (NT is a multiple of CV: the channel group of a thread is fixed)
+  auto gload_into = [&](int tile, auto& ri) {
     int pt = tile;
     const int tx0 = (pt % tiles_x) * TW; pt /= tiles_x;
     const int ty0 = (pt % tiles_y) * TH; pt /= tiles_y;
     const int b = pt;
+    const unsigned ibase = (unsigned)((b * a.H + ty0) * a.W + tx0) * (unsigned)a.in_ld;
+    const unsigned omask = (ty0 == 0 ? 1u : 0u) | (ty0 + TH >= a.H ? 2u : 0u) | (tx0 == 0 ? 4u : 0u) | (tx0 + TW >= a.W ? 8u : 0u) | 16u;
 #pragma unroll
     for (int k = 0; k < NVI; ++k) {
-      const int i = tid + k * NT;
-      const int ii = i < NVI_TOT ? i : 0;
-      const int pix = ii / CV, cv = ii - pix * CV;
-      const int hy = pix / IW, hx = pix - hy * IW;
-      const int gy = ty0 + hy - PADP, gx = tx0 + hx - PADP;
-      const bool inimg = i < NVI_TOT && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
-      const size_t off = inimg ? ((size_t)(b * a.H + gy) * a.W + gx) * a.in_ld + cv * 8 : (size_t)0;
+      const bool inimg = ((hedge >> (5 * k)) & omask) == 0;
+      const unsigned off = ibase + (unsigned)hoff[k];
 #pragma unroll
       for (int c = 0; c < NCH; ++c) {
-        const bool ok = inimg && c * KC + cv * 8 < a.Cin;
-        // (element offset of the zero page relative to `in`: one offset select per vector, as branch-free as the dummy-address form)
-        const V16 v = *reinterpret_cast<const V16*>(in + (ok ? (ptrdiff_t)(off + c * KC) : zoff));   // no post-processing: stays in flight
+        // (element offset of the zero page relative to `in`: one offset select per vector, no post-processing: the load stays in flight)
+        const V16 v = *reinterpret_cast<const V16*>(in + ((inimg && chan_ok[c]) ? (ptrdiff_t)(off + (unsigned)(c * KC)) : zoff));
         ri[c][k].w[0] = v.w[0]; ri[c][k].w[1] = v.w[1]; ri[c][k].w[2] = v.w[2]; ri[c][k].w[3] = v.w[3];
       }
     }
   };
-  auto lstore = [&](int buf) {
+  auto lstore_from = [&](int buf, const auto& ri) {
 #pragma unroll
     for (int k = 0; k < NVI; ++k) {
       const int i = tid + k * NT;
@@ -815,55 +804,91 @@ __global__ __launch_bounds__(64 * WM * WN, (GNB && NCH == 1 && WN == 1) ? 2 : 1)
       }
     }
   };
+  auto gload = [&](int tile) { gload_into(tile, ri); };
+  auto lstore = [&](int buf) { lstore_from(buf, ri); };
 
   // XCD-aware walk: block b handles tiles b, b + G, ...; neighbouring blocks work on neighbouring tiles at the same time
-  int tile = blockIdx.x;
-  int cur = 0;
-  if (tile < ntiles) { gload(tile); lstore(0); }
-  __syncthreads();
-  for (; tile < ntiles; tile += gridDim.x) {
-    const int nxt = tile + gridDim.x;
-    if (nxt < ntiles) gload(nxt);
+  const int tiles_img = tiles_x * tiles_y;
+  unsigned lpix[NTM * 2];
+  conv3_epilogue_lanes<NTM, TW>(l, wm, a.W, lpix);
+  // the MFMAs + epilogue of one tile out of LDS buffer `cur`
+  auto compute = [&](int tile, int cur) {
     f32x16 acc[NTM];
 #pragma unroll
     for (int j = 0; j < NTM; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] = GNB ? 0.f : bq[GNB ? 0 : r];
+    // software-pipelined over the NCH * TAPS * 2 (chunk, tap, k-step) groups: the LDS fragment reads of group g + 2 are issued before
+    // the MFMAs of group g (sched_barrier keeps the blocks apart).  Left to the compiler the loop came out as read -> lgkmcnt(0) ->
+    // MFMA, 36 times per tile: every MFMA waited out a full LDS round trip, which - not HBM - bounded this kernel.
+    {
+      constexpr int NG = NCH * TAPS * 2, LA = 2;               // groups, look-ahead
+      typename M::Frag fb[LA + 1][NTM];
+      const T* sb0 = sIn + cur * BUF;
+      auto rd = [&](int g, int slot) {
+        const int c = g / (TAPS * 2), t = (g >> 1) % TAPS, kk = g & 1;
+        const int off = c * CHB + ((t / KS) * IW + (t % KS)) * KCP + kk * 16;
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) {
-      const T* sb = sIn + cur * BUF + c * CHB;
+        for (int j = 0; j < NTM; ++j) fb[slot][j] = *reinterpret_cast<const typename M::Frag*>(sb0 + pbase[j] + off);
+      };
 #pragma unroll
-      for (int t = 0; t < TAPS; ++t) {
-        const int toff = ((t / KS) * IW + (t % KS)) * KCP;
+      for (int g = 0; g < LA && g < NG; ++g) rd(g, g);
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-          typename M::Frag fb[NTM];
+      for (int g = 0; g < NG; ++g) {
+        if (g + LA < NG) rd(g + LA, (g + LA) % (LA + 1));
+        __builtin_amdgcn_sched_barrier(0);
+        const int c = g / (TAPS * 2), t = (g >> 1) % TAPS, kk = g & 1;
 #pragma unroll
-          for (int j = 0; j < NTM; ++j) fb[j] = *reinterpret_cast<const typename M::Frag*>(sb + pbase[j] + toff + kk * 16);
-#pragma unroll
-          for (int j = 0; j < NTM; ++j) acc[j] = M::mfma(fa[c][t][kk], fb[j], acc[j]);
-        }
+        for (int j = 0; j < NTM; ++j) acc[j] = M::mfma(fa[c][t][kk], fb[g % (LA + 1)][j], acc[j]);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     // ---- epilogue of this tile (wave-private staging, no block barrier needed)
-    {
-      int pt = tile;
-      const int tx0 = (pt % tiles_x) * TW; pt /= tiles_x;
-      const int ty0 = (pt % tiles_y) * TH; pt /= tiles_y;
-      const int b = pt;
+    const int txy = tile % tiles_img, b = tile / tiles_img;
+    const int tx0 = (txy % tiles_x) * TW, ty0 = (txy / tiles_x) * TH;
 #pragma unroll
-      for (int j = 0; j < NTM; ++j) {
+    for (int j = 0; j < NTM; ++j) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float v[4] = {acc[j][4 * q], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]};
-          store4<T>(stage + (j * 32 + (l & 31)) * ERS + 8 * q + 4 * (l >> 5), v);
-        }
+      for (int q = 0; q < 4; ++q) {
+        float v[4] = {acc[j][4 * q], acc[j][4 * q + 1], acc[j][4 * q + 2], acc[j][4 * q + 3]};
+        store4<T>(stage + (j * 32 + (l & 31)) * ERS + 8 * q + 4 * (l >> 5), v);
       }
-      conv3_epilogue_store<T, NTM, TW, TH, WM, GNB>(a, stage, l, wm, ct, b, ty0, tx0, tiles_x, tiles_y);
     }
-    if (nxt < ntiles) lstore(cur ^ 1);
+    conv3_epilogue_store<T, NTM, TW, TH, WM, GNB>(a, stage, l, wm, ct, b, (unsigned)((b * a.H + ty0) * a.W + tx0), txy, tiles_img, lpix);
+  };
+  const int G = gridDim.x;
+  int tile = blockIdx.x;
+  int cur = 0;
+  if constexpr (PF == 2) {
+    // two register sets: while tile t is multiplied, the halo tiles of t + G and t + 2 G (or t + 2 G and t + 3 G) are in flight
+    if (tile < ntiles) { gload_into(tile, ri); lstore_from(0, ri); }
+    if (tile + G < ntiles) gload_into(tile + G, ri);
+    if (tile + 2 * G < ntiles) gload_into(tile + 2 * G, rj);
     __syncthreads();
-    cur ^= 1;
+    for (; tile < ntiles; tile += 2 * G) {
+      compute(tile, cur);
+      if (tile + G < ntiles) lstore_from(cur ^ 1, ri);
+      if (tile + 3 * G < ntiles) gload_into(tile + 3 * G, ri);
+      __syncthreads();
+      cur ^= 1;
+      if (tile + G >= ntiles) break;
+      compute(tile + G, cur);
+      if (tile + 2 * G < ntiles) lstore_from(cur ^ 1, rj);
+      if (tile + 4 * G < ntiles) gload_into(tile + 4 * G, rj);
+      __syncthreads();
+      cur ^= 1;
+    }
+  } else {
+    if (tile < ntiles) { gload(tile); lstore(0); }
+    __syncthreads();
+    for (; tile < ntiles; tile += G) {
+      const int nxt = tile + G;
+      if (nxt < ntiles) gload(nxt);
+      compute(tile, cur);
+      if (nxt < ntiles) lstore(cur ^ 1);
+      __syncthreads();
+      cur ^= 1;
+    }
   }
 }
 
@@ -871,19 +896,26 @@ template <typename T, int KS, int TH, int TW, int WM, int WN, int NCH>
 static hipError_t launch_conv3p_cfg(const ConvArgs& a0, hipStream_t s) {
   ConvArgs a = a0;
   stat_resolve(a, (a.W / TW) * (a.H / TH) * WM);
-  if (KS != 3) a.gnb.x = nullptr;                             // the dv epilogue is instantiated for the 3x3 kernels only
+  if (KS != 3 || WN != 1) a.gnb.x = nullptr;                  // the dv epilogue: 3x3 kernels, one cout tile per block (<= 32 planes) - a wave of
+                                                              // the cout-split forms walks 8-16 vectors per tile, whose prefetch registers
+                                                              // cost more than the fused pass saves (254 vs 80 us measured at 64 planes)
   gnb_resolve(a, (a.W / TW) * (a.H / TH) * WM);
   constexpr int TAPS = KS * KS, PADP = KS / 2;
   constexpr int IH = TH + 2 * PADP, IW = TW + 2 * PADP, KCP = KC + MM<T>::PAD, BN = 32 * WN;
   constexpr size_t lds = ((size_t)2 * NCH * IH * IW * KCP + (size_t)(TH * TW / (32 * WM)) * 32 * 40 * WM * WN) * sizeof(T);
   static_assert(lds <= 160 * 1024, "conv3p LDS");
   void (*kern)(ConvArgs) = conv3p_kernel<T, KS, TH, TW, WM, WN, NCH>;
-  if constexpr (KS == 3) { if (a.gnb.x) kern = conv3p_kernel<T, KS, TH, TW, WM, WN, NCH, true>; }
-  static AttrOnce attr_once[2];
-  if (!attr_once[a.gnb.x ? 1 : 0].cur()) {
+  int kidx = 0;
+  if constexpr (KS == 3 && WN == 1) { if (a.gnb.x) { kern = conv3p_kernel<T, KS, TH, TW, WM, WN, NCH, true>; kidx = 1; } }
+  if constexpr (KS == 3 && WN == 1 && NCH == 1) {
+    static const int pf = getenv("PU_CONV3P_PF") ? atoi(getenv("PU_CONV3P_PF")) : 1;
+    if (pf == 2 && !a.gnb.x) { kern = conv3p_kernel<T, KS, TH, TW, WM, WN, NCH, false, 2>; kidx = 2; }
+  }
+  static AttrOnce attr_once[3];
+  if (!attr_once[kidx].cur()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    attr_once[a.gnb.x ? 1 : 0].cur() = true;
+    attr_once[kidx].cur() = true;
   }
   const int ntiles = (a.W / TW) * (a.H / TH) * a.B;
   const int gy = cdiv(a.Cout, BN);
@@ -909,7 +941,13 @@ static hipError_t launch_conv3p(const ConvArgs& a, hipStream_t s) {
     if (nch == 1) return launch_conv3p_cfg<T, KS, TH, TW, 1, 4, 1>(a, s);
     return hipErrorNotSupported;                              // 2 chunks + 80 KB staging exceed the LDS
   }
-  if (a.Cout > 32) return nch == 1 ? launch_conv3p_cfg<T, KS, TH, TW, 2, 2, 1>(a, s) : launch_conv3p_cfg<T, KS, TH, TW, 2, 2, 2>(a, s);
+  if (a.Cout > 32) {
+    // 64 -> 64 class, PU_C64_MODE=3: ONE 8-wave block per CU (4 pixel quarters x 2 cout tiles), every weight fragment of the layer
+    // resident in registers (144 per lane), 2 waves per SIMD: no weight traffic from L2 after the prologue
+    static const int c64_mode = getenv("PU_C64_MODE") ? atoi(getenv("PU_C64_MODE")) : 1;
+    if (nch == 2 && c64_mode == 3) return launch_conv3p_cfg<T, KS, TH, TW, 4, 2, 2>(a, s);
+    return nch == 1 ? launch_conv3p_cfg<T, KS, TH, TW, 2, 2, 1>(a, s) : launch_conv3p_cfg<T, KS, TH, TW, 2, 2, 2>(a, s);
+  }
   return nch == 1 ? launch_conv3p_cfg<T, KS, TH, TW, 4, 1, 1>(a, s) : launch_conv3p_cfg<T, KS, TH, TW, 4, 1, 2>(a, s);
 }
 
@@ -920,7 +958,7 @@ static hipError_t launch_conv3_cfg(const ConvArgs& a0, hipStream_t s) {
   }
   ConvArgs a = a0;
   stat_resolve(a, (a.W / TW) * (a.H / TH) * WM);
-  if (KS != 3) a.gnb.x = nullptr;                             // the dv epilogue is instantiated for the 3x3 kernels only
+  if (KS != 3 || WN != 1) a.gnb.x = nullptr;                  // (see launch_conv3p_cfg)
   gnb_resolve(a, (a.W / TW) * (a.H / TH) * WM);
   constexpr int TAPS = KS * KS, PADP = KS / 2;
   constexpr int IH = TH + 2 * PADP, IW = TW + 2 * PADP, KCP = KC + (MS == 16 ? 16 : MM<T>::PAD), BN = 32 * WN;
@@ -929,7 +967,7 @@ static hipError_t launch_conv3_cfg(const ConvArgs& a0, hipStream_t s) {
   constexpr size_t lds_ep = (size_t)(TH * TW / (32 * WM)) * 32 * 40 * WM * WN * sizeof(T);      // epilogue staging, wave-private
   constexpr size_t lds = lds_in > lds_ep ? lds_in : lds_ep;
   void (*kern)(ConvArgs) = conv3_kernel<T, KS, TH, TW, WM, WN, MS>;
-  if constexpr (KS == 3) { if (a.gnb.x) kern = conv3_kernel<T, KS, TH, TW, WM, WN, MS, true>; }
+  if constexpr (KS == 3 && WN == 1) { if (a.gnb.x) kern = conv3_kernel<T, KS, TH, TW, WM, WN, MS, true>; }
   static AttrOnce attr_once[2];
   if (!attr_once[a.gnb.x ? 1 : 0].cur()) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

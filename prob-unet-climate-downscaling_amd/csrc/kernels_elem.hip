@@ -475,13 +475,15 @@ __global__ __launch_bounds__(256) void gn_bwd_pass1_kernel(GNBwdArgs a) {
       const T* dyp = reinterpret_cast<const T*>(a.dy.p);
       const uint32_t dkey = drop_key(f.drop_seed, f.drop_stream), dthr = drop_thr16(keep);
       for (long p = p0 + pl; p < p1; p += (long)PL * U) {
-        V16 rx[U], rd[U];
-#pragma unroll
+        V16 rx[U], rd[U]; uint32_t kbv[U];
+        const bool saved = VEC == 8 && f.drop_p > 0.f && f.keep_bits != nullptr;      // keep decisions saved by the forward: fetched with
+#pragma unroll                                                                        // the tensors, not behind their wait
         for (int u = 0; u < U; ++u) {
           const long pp = p + (long)u * PL;
           const long q = pp < p1 ? pp : p;                          // clamp: the duplicate is discarded below
           rx[u] = ldv<T>(xp + ((long)b * HW + q) * f.x.ld + cv * VEC);
           rd[u] = ldv<T>(dyp + ((long)b * HW + q) * a.dy.ld + cv * VEC);
+          kbv[u] = saved ? (uint32_t)f.keep_bits[(((uint64_t)(b + f.b0) * HW + q) * (uint64_t)C + (uint64_t)(cv * VEC)) >> 3] : 0u;
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -491,7 +493,7 @@ __global__ __launch_bounds__(256) void gn_bwd_pass1_kernel(GNBwdArgs a) {
             unpack<T>(rx[u], xv); unpack<T>(rd[u], dh);
             if (f.drop_p > 0.f) {
               const uint64_t base = ((uint64_t)(b + f.b0) * HW + pp) * (uint64_t)C + (uint64_t)(cv * VEC);
-              const uint32_t kb = drop_keep_bits<VEC, true>(f, dkey, dthr, base);
+              const uint32_t kb = saved ? kbv[u] : drop_keep_bits<VEC>(f, dkey, dthr, base);
 #pragma unroll
               for (int e = 0; e < VEC; ++e) dh[e] = ((kb >> e) & 1u) ? dh[e] * inv_keep : 0.f;
             }
@@ -624,7 +626,8 @@ __global__ __launch_bounds__(256) void gn_bwd_pass2_kernel(GNBwdArgs a) {
     const T* dyp = reinterpret_cast<const T*>(a.dy.p);
     const uint32_t dkey = drop_key(f.drop_seed, f.drop_stream), dthr = drop_thr16(keep);
     for (long p = p0 + pl; p < p1; p += (long)PL * U) {
-      V16 rx[U], rd[U], ro[U], ra[U];
+      V16 rx[U], rd[U], ro[U], ra[U]; uint32_t kbv[U];
+      const bool saved = !DV && VEC == 8 && f.drop_p > 0.f && f.keep_bits != nullptr;
       const T* addp = reinterpret_cast<const T*>(a.add.p);
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -632,6 +635,7 @@ __global__ __launch_bounds__(256) void gn_bwd_pass2_kernel(GNBwdArgs a) {
         const long bp = (long)b * HW + (pp < p1 ? pp : p);
         rx[u] = ldv<T>(xp + bp * f.x.ld + cv * VEC);
         rd[u] = ldv<T>(dyp + bp * a.dy.ld + cv * VEC);
+        kbv[u] = saved ? (uint32_t)f.keep_bits[(((uint64_t)f.b0 * HW + (uint64_t)bp) * (uint64_t)C + (uint64_t)(cv * VEC)) >> 3] : 0u;
         if (a.accumulate) ro[u] = ldv<T>(dxp + bp * a.dx.ld + cv * VEC);
         if (addp) ra[u] = ldv<T>(addp + bp * a.add.ld + cv * VEC);
       }
@@ -643,7 +647,7 @@ __global__ __launch_bounds__(256) void gn_bwd_pass2_kernel(GNBwdArgs a) {
           unpack<T>(rx[u], xv); unpack<T>(rd[u], dh);
           if (!DV && f.drop_p > 0.f) {
             const uint64_t base = ((uint64_t)(b + f.b0) * HW + pp) * (uint64_t)C + (uint64_t)(cv * VEC);
-            const uint32_t kb = drop_keep_bits<VEC, true>(f, dkey, dthr, base);
+            const uint32_t kb = saved ? kbv[u] : drop_keep_bits<VEC>(f, dkey, dthr, base);
 #pragma unroll
             for (int e = 0; e < VEC; ++e) dh[e] = ((kb >> e) & 1u) ? dh[e] * inv_keep : 0.f;
           }
@@ -735,12 +739,16 @@ __global__ __launch_bounds__(256) void gn_small_bwd_kernel(GNBwdArgs a, int CB) 
 #pragma unroll
     for (int e = 0; e < VEC; ++e) { const float4 q4 = q1[e]; A[e] = q4.x; Bc[e] = q4.y; mu[e] = q4.z; rs[e] = q4.w; s1[e] = 0.f; s2[e] = 0.f; }
   }
-  auto dv_of = [&](long p, const V16& rx, const V16& rd, float* xv, float* dv) {
+  const bool saved = f.drop_p > 0.f && f.keep_bits != nullptr;
+  auto kb_load = [&](long p) -> uint32_t {
+    return saved ? (uint32_t)f.keep_bits[(((uint64_t)(b + f.b0) * HW + p) * (uint64_t)C + (uint64_t)(c0 + cv * VEC)) >> 3] : 0u;
+  };
+  auto dv_of = [&](long p, const V16& rx, const V16& rd, uint32_t kbs, float* xv, float* dv) {
     float dh[VEC];
     unpack<T>(rx, xv); unpack<T>(rd, dh);
     if (f.drop_p > 0.f) {
       const uint64_t base = ((uint64_t)(b + f.b0) * HW + p) * (uint64_t)C + (uint64_t)(c0 + cv * VEC);
-      const uint32_t kb = drop_keep_bits<VEC, true>(f, dkey, dthr, base);
+      const uint32_t kb = saved ? kbs : drop_keep_bits<VEC>(f, dkey, dthr, base);
 #pragma unroll
       for (int e = 0; e < VEC; ++e) dh[e] = ((kb >> e) & 1u) ? dh[e] * inv_keep : 0.f;
     }
@@ -750,18 +758,18 @@ __global__ __launch_bounds__(256) void gn_small_bwd_kernel(GNBwdArgs a, int CB) 
   constexpr int U = 4;                                        // pixels per trip, every load issued before the first use
   if (act) {
     for (long p = pl; p < HW; p += (long)U * PL) {
-      V16 rx[U], rd[U];
+      V16 rx[U], rd[U]; uint32_t kbv[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const long pp = p + (long)u * PL, q = pp < HW ? pp : p;
-        rx[u] = ldv<T>(xp + q * f.x.ld); rd[u] = ldv<T>(dyp + q * a.dy.ld);
+        rx[u] = ldv<T>(xp + q * f.x.ld); rd[u] = ldv<T>(dyp + q * a.dy.ld); kbv[u] = kb_load(q);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const long pp = p + (long)u * PL;
         if (pp < HW) {
           float xv[VEC], dv[VEC];
-          dv_of(pp, rx[u], rd[u], xv, dv);
+          dv_of(pp, rx[u], rd[u], kbv[u], xv, dv);
 #pragma unroll
           for (int e = 0; e < VEC; ++e) { s1[e] += dv[e]; s2[e] += dv[e] * (xv[e] - mu[e]) * rs[e]; }
         }
@@ -802,11 +810,11 @@ __global__ __launch_bounds__(256) void gn_small_bwd_kernel(GNBwdArgs a, int CB) 
 #pragma unroll
   for (int e = 0; e < VEC; ++e) { o0[e] = cof[(cv * VEC + e) * 3]; o1[e] = cof[(cv * VEC + e) * 3 + 1]; o2[e] = cof[(cv * VEC + e) * 3 + 2]; }
   for (long p = pl; p < HW; p += (long)U * PL) {              // second read of x / dy (L2 hits), again four pixels per trip
-    V16 rx[U], rd[U], ro[U], ra[U];
+    V16 rx[U], rd[U], ro[U], ra[U]; uint32_t kbv[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const long pp = p + (long)u * PL, q = pp < HW ? pp : p;
-      rx[u] = ldv<T>(xp + q * f.x.ld); rd[u] = ldv<T>(dyp + q * a.dy.ld);
+      rx[u] = ldv<T>(xp + q * f.x.ld); rd[u] = ldv<T>(dyp + q * a.dy.ld); kbv[u] = kb_load(q);
       if (a.accumulate) ro[u] = ldv<T>(dxp + q * a.dx.ld);
       if (addp) ra[u] = ldv<T>(addp + q * a.add.ld);
     }
@@ -825,7 +833,7 @@ __global__ __launch_bounds__(256) void gn_small_bwd_kernel(GNBwdArgs a, int CB) 
 #pragma unroll
           for (int e = 0; e < VEC; ++e) o[e] += av[e];
         }
-        dv_of(pp, rx[u], rd[u], xv, dv);
+        dv_of(pp, rx[u], rd[u], kbv[u], xv, dv);
 #pragma unroll
         for (int e = 0; e < VEC; ++e) o[e] += o0[e] * dv[e] + o1[e] * (xv[e] - mu[e]) + o2[e];
         stv<T>(dxp + pp * a.dx.ld, pack<T>(o));

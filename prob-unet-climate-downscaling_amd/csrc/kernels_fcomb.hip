@@ -310,13 +310,18 @@ __device__ __forceinline__ void fc_forward_tile(const FcW<T>& w, const typename 
 template <typename T>
 __global__ __launch_bounds__(256) void fcomb_fwd16_kernel(FcombArgs f, const float* __restrict__ zb) {
   typedef FCM<T> M;
+  extern __shared__ __attribute__((aligned(16))) float fcf_zbs[];      // [M][32]: this sample's per-member latent bias
   const long HW = (long)f.feat.H * f.feat.W;
   const int b = blockIdx.y, l = threadIdx.x & 63, wave = threadIdx.x >> 6, j = l & 31, h = l >> 5;
   const uint16_t* fp = reinterpret_cast<const uint16_t*>(f.feat.p) + (f.bcast ? 0 : (long)b * HW * f.feat.ld);
+  // the member loop used to fetch its 16 bias values from global memory with a wait behind every load (4 dependent L2 round trips per
+  // member in front of a 6-MFMA chain): staged once per block instead, read back as four 16-byte LDS vectors per member
+  for (int i = threadIdx.x; i < f.M * 32; i += 256) fcf_zbs[i] = zb[((long)(i >> 5) * f.B + b) * 32 + (i & 31)];
   FcW<T> w; fc_load_fwd_weights<T>(f, l, w);
   float b1r[16], b2r[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) { b1r[r] = f.b1[fc_row(r, h)]; b2r[r] = fc_row(r, h) < f.Cout ? f.b2[fc_row(r, h)] : 0.f; }
+  __syncthreads();
   const long ntile = (HW + 31) / 32;
   for (long t = (long)blockIdx.x * 4 + wave; t < ntile; t += (long)gridDim.x * 4) {
     const long pix = t * 32 + j;
@@ -335,10 +340,15 @@ __global__ __launch_bounds__(256) void fcomb_fwd16_kernel(FcombArgs f, const flo
     pre = M::mfma(w.w0n[0], fb[0], pre);
     pre = M::mfma(w.w0n[1], fb[1], pre);
     for (int m = 0; m < f.M; ++m) {
-      const float* zbm = zb + ((long)m * f.B + b) * 32;
+      // rows fc_row(r, h) = (r & 3) + 8 (r >> 2) + 4 h: registers 4 g .. 4 g + 3 are the contiguous rows 8 g + 4 h ..
+      const f32x4* zq = reinterpret_cast<const f32x4*>(fcf_zbs + m * 32 + 4 * h);
       f32x16 h0, acc;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) h0[r] = fmaxf(pre[r] + zbm[fc_row(r, h)], 0.f);
+      for (int g4 = 0; g4 < 4; ++g4) {
+        const f32x4 z4 = zq[2 * g4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) h0[4 * g4 + e] = fmaxf(pre[4 * g4 + e] + z4[e], 0.f);
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = b1r[r];
       acc = M::mfma(w.w1p[0], fc_acc_frag<T>(h0, 0), acc);
@@ -350,7 +360,13 @@ __global__ __launch_bounds__(256) void fcomb_fwd16_kernel(FcombArgs f, const flo
       for (int r = 0; r < 16; ++r) acc[r] = b2r[r];
       acc = M::mfma(w.w2p[0], fc_acc_frag<T>(h1, 0), acc);
       acc = M::mfma(w.w2p[1], fc_acc_frag<T>(h1, 1), acc);
-      if (valid) {
+      if (f.Cout <= 4) {                                     // (uniform) rows 0..3 live in registers 0..3 of the h == 0 half
+        if (valid && h == 0) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (r < f.Cout) f.out[(((long)b * f.M + m) * f.Cout + r) * HW + pix] = fcomb_emit(f, b, r, pix, HW, acc[r]);
+        }
+      } else if (valid) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int co = fc_row(r, h);
@@ -674,7 +690,7 @@ hipError_t launch_fcomb_fwd(const FcombArgs& a, hipStream_t s) {
       // a third round two thirds empty at B = 32; measured neutral to +0.4 % per step)
       const long per_sample = 768 / (a.B > 0 ? a.B : 1) > 0 ? 768 / (a.B > 0 ? a.B : 1) : 1;
       dim3 g16((unsigned)min(per_sample, (HW + 127) / 128), a.B);
-      hipLaunchKernelGGL((fcomb_fwd16_kernel<T>), g16, dim3(256), 0, s, a, zb);
+      hipLaunchKernelGGL((fcomb_fwd16_kernel<T>), g16, dim3(256), (size_t)a.M * 32 * sizeof(float), s, a, zb);
     }
   } else if (a.F == 32) hipLaunchKernelGGL((fcomb_fwd_kernel<T, 32>), grid, dim3(256), 0, s, a, zb);
   else if (a.F == 16) hipLaunchKernelGGL((fcomb_fwd_kernel<T, 16>), grid, dim3(256), 0, s, a, zb);

@@ -19,17 +19,6 @@
 
 #include "pu_kernels.h"
 
-// Diagnostic builds only (tools/ablate_wgrad.sh; results are WRONG by design): -DPU_WG_ABLATE=<bits> removes one ingredient of the main
-// kernel at a time - 1: one B fragment per K-step instead of one per tap (LDS read traffic 12 -> 4 reads per step), 2: no barrier in
-// the tile loop, 4: no global loads / LDS stores after the first tile, 8: no MFMAs, 16: no slab stores, 32: no global loads after the first tile (the LDS stores stay).
-#ifndef PU_WG_ABLATE
-#define PU_WG_ABLATE 0
-#endif
-#ifndef PU_WG_LATE_STORE
-#define PU_WG_LATE_STORE 1        // 1 (default): the staged vectors of the next tile are written to LDS in one burst after the K-steps;
-                                  // 0: between the MFMA groups of the last K-steps - measured neutral to 5 % slower (profiles/r2_ab_runs.txt)
-#endif
-
 namespace pu {
 
 typedef short s16x4v __attribute__((ext_vector_type(4)));
@@ -57,7 +46,6 @@ __device__ __forceinline__ Frag tr_frag(const uint16_t* p0, const uint16_t* p1) 
 template <typename T, int KS, int TH, int TW, int BCI, int NW, int BCO>
 __global__ __launch_bounds__(64 * NW) void conv_wgrad16_kernel(WgradArgs a) {
   typedef MMW<T> M;
-  constexpr bool LATE_STORE = PU_WG_LATE_STORE != 0;
   constexpr int NTH = 64 * NW;
   constexpr int TAPS = KS * KS, PADP = KS / 2;
   constexpr int BM = TH * TW;
@@ -81,6 +69,9 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad16_kernel(WgradArgs a) {
   const int ct = wave % COS;
   const int it = (wave / COS) % CIS;
   const int tap0 = (wave / (COS * CIS)) * NJ;
+  // a tap group entirely beyond the last tap (the fourth group of 9 = 3 + 3 + 3) only helps with the staging; readfirstlane makes the
+  // test a scalar branch (one per K-step) instead of exec-mask juggling around every MFMA
+  const bool grp_live = __builtin_amdgcn_readfirstlane(tap0) < TAPS;
   const int co0 = blockIdx.y * BCO, ci0 = blockIdx.z * BCI;
   const int tiles_x = a.W / TW, tiles_y = a.H / TH;
   const int ntiles = tiles_x * tiles_y * a.B;
@@ -159,7 +150,7 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad16_kernel(WgradArgs a) {
   __syncthreads();
   for (; tile < ntiles; tile += gridDim.x) {
     const int nxt = tile + gridDim.x;
-    if (nxt < ntiles && !(PU_WG_ABLATE & (4 | 32))) gload(nxt);
+    if (nxt < ntiles) gload(nxt);
     const uint16_t* sDy = lds + cur * BUF + (ct * BM) * 32 + cb;
     const uint16_t* sA = lds + cur * BUF + COS * BM * 32 + (it * NPH) * 32 + cb;
     // software-pipelined over the K-steps: the transposed reads of step kk+1 are issued as one block before the MFMAs of step
@@ -174,8 +165,7 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad16_kernel(WgradArgs a) {
         const int t = tap0 + j;
         const int tt = t < TAPS ? t : 0;
         const int toff = ((tt / KS) * IW + (tt % KS)) * 32;
-        if ((PU_WG_ABLATE & 1) && j > 0) fb[slot][j] = fb[slot][0];
-        else fb[slot][j] = tr_frag<typename M::Frag>(sA + h0 + toff, sA + h1 + toff);
+        fb[slot][j] = tr_frag<typename M::Frag>(sA + h0 + toff, sA + h1 + toff);
       }
     };
     load_step(0, 0);
@@ -183,18 +173,13 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad16_kernel(WgradArgs a) {
     for (int kk = 0; kk < BM / 16; ++kk) {
       if (kk + 1 < BM / 16) load_step(kk + 1, (kk + 1) & 1);
       __builtin_amdgcn_sched_barrier(0);
+      // every wave multiplies all NJ slots: a slot beyond the last tap (the second tap group of 9 = 5 + 4) re-reads tap 0 and its result is
+      // never stored.  The guard `if (tap0 + j < TAPS)` that used to sit here depends on the wave index, which the compiler treats as
+      // divergent: each MFMA ended up in its own exec-masked basic block behind a branch pair (40 per tile and wave) - the reason this
+      // kernel sat at 28 % MFMA utilisation with its waves marching through load / multiply phases together.
+      if (grp_live) {
 #pragma unroll
-      for (int j = 0; j < NJ; ++j)
-        if (tap0 + j < TAPS) {
-          if (PU_WG_ABLATE & 8) acc[j][0] += (float)fa[kk & 1][0] * (float)fb[kk & 1][j][0];
-          else acc[j] = M::mfma(fa[kk & 1], fb[kk & 1][j], acc[j]);
-        }
-      // the next tile's staged vectors go to the other LDS buffer BETWEEN the MFMA groups of the last K-steps (ds_write issues beside
-      // the matrix pipe) instead of in one burst after them, when every wave of the block would be writing and none multiplying
-      if (!LATE_STORE && nxt < ntiles && !(PU_WG_ABLATE & 4)) {
-#pragma unroll
-        for (int p = 0; p < NPARTS; ++p)
-          if (STEPS - 1 - (NPARTS - 1 - p) * STEPS / NPARTS == kk) lstore_part(cur ^ 1, p);
+        for (int j = 0; j < NJ; ++j) acc[j] = M::mfma(fa[kk & 1], fb[kk & 1][j], acc[j]);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -207,9 +192,10 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad16_kernel(WgradArgs a) {
         bsum += ET<T>::ld(&v);
       }
     }
-    if (LATE_STORE && nxt < ntiles && !(PU_WG_ABLATE & 4)) lstore(cur ^ 1);
-    if (!(PU_WG_ABLATE & 2)) __syncthreads();
-    if (!(PU_WG_ABLATE & 4)) cur ^= 1;
+    if (nxt < ntiles) lstore(cur ^ 1);          // (the next tile's vectors in one burst after the K-steps; spreading them between the MFMA
+                                                //  groups of the last K-steps measured neutral to 5 % slower, profiles/r2_ab_runs.txt)
+    __syncthreads();
+    cur ^= 1;
   }
   if (do_bias) {                                  // combine the pixel parts, one partial row per split
     float* red = reinterpret_cast<float*>(smem_raw);
@@ -231,7 +217,7 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad16_kernel(WgradArgs a) {
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int t = tap0 + j;
-    if (t < TAPS && (!(PU_WG_ABLATE & 16) || acc[j][0] == 12345.f)) {
+    if (t < TAPS) {
       const int ci = ci0 + it * 32 + (l & 31);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
