@@ -86,6 +86,9 @@ int64_t pu_param_count(pu_ctx* ctx);               /* number of fp32 elements in
 /* flat_params / flat_grads: device fp32 arrays of pu_param_count elements. Gradients are WRITTEN (not
  * accumulated) by pu_elbo_fwd_bwd and the *_bwd calls that state so. */
 int pu_bind_params(pu_ctx* ctx, float* flat_params, float* flat_grads);
+/* Move the gradient destination only (same layout, another device buffer): lets a caller alternate between two gradient buffers so that
+ * gradients it still references are not overwritten by the next fused backward.  Does not invalidate the packed weights. */
+int pu_bind_grads(pu_ctx* ctx, float* flat_grads);
 /* Tell the engine the fp32 master weights changed (optimizer step / load_state_dict): low-precision packed
  * copies are rebuilt on the next call. */
 int pu_params_changed(pu_ctx* ctx);

@@ -60,6 +60,7 @@ def lib():
     L.pu_param_count.restype = i64; L.pu_param_count.argtypes = [vp]
     L.pu_workspace_bytes.restype = i64; L.pu_workspace_bytes.argtypes = [vp]
     L.pu_bind_params.restype = i32; L.pu_bind_params.argtypes = [vp, vp, vp]
+    L.pu_bind_grads.restype = i32; L.pu_bind_grads.argtypes = [vp, vp]
     L.pu_params_changed.restype = i32; L.pu_params_changed.argtypes = [vp]
     L.pu_unet_fwd.restype = i32; L.pu_unet_fwd.argtypes = [vp, vp, vp, i32, i32, u64, vp]
     L.pu_unet_bwd.restype = i32; L.pu_unet_bwd.argtypes = [vp, vp, vp]

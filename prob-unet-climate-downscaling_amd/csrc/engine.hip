@@ -938,6 +938,11 @@ int pu_bind_params(pu_ctx* c, float* p, float* g) {
   c->params = p; c->grads = g; c->packed_valid = false;
   return PU_OK;
 }
+int pu_bind_grads(pu_ctx* c, float* g) {
+  if (!c || !g) return PU_ERR_INVALID;
+  c->grads = g;                          // the packed compute-dtype weights stay valid: only the gradient destination moves
+  return PU_OK;
+}
 int pu_params_changed(pu_ctx* c) { if (!c) return PU_ERR_INVALID; c->packed_valid = false; return PU_OK; }
 
 double pu_elbo_fwd_flops(pu_ctx* c, int B, int M) {

@@ -1327,6 +1327,31 @@ __global__ __launch_bounds__(256) void pack_frag_kernel(const float* __restrict_
     const int ct = tile / nch, c = tile - ct * nch;
     __syncthreads();                                       // previous tile's reads are done
     // run q (0..31) = cout index within the tile's cout range; elements = (cin offset within the tile's cin range) * taps + tap
+    const int cbase = (dgrad ? ct : c) * 32, rbase = (dgrad ? c : ct) * 32;
+    const bool fast = (d.src_off & 3) == 0 && (d.Cin & 3) == 0 && cbase + 32 <= d.Cin && rbase + 32 <= d.Cout &&
+                      (reinterpret_cast<uintptr_t>(params) & 15) == 0;           // whole 32 x 32 tile, 16-byte aligned rows
+    if (fast) {
+      // 16-byte loads: a row is run / 4 float4 (the 4-byte form issued 36 scalar loads per thread and ran at 1.7 TB/s of traffic)
+      const int run4 = run >> 2;                             // 72 (3x3) or 8 (1x1) vectors per row
+      constexpr int U4 = 9;
+      f32x4 tv[U4];
+#pragma unroll
+      for (int u = 0; u < U4; ++u) {
+        const int i = u * 256 + tid;
+        const int q = i / run4, o4 = i - q * run4;
+        tv[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (i < 32 * run4) tv[u] = *reinterpret_cast<const f32x4*>(w + ((size_t)(rbase + q) * d.Cin + cbase) * taps + 4 * o4);
+      }
+#pragma unroll
+      for (int u = 0; u < U4; ++u) {
+        const int i = u * 256 + tid;
+        if (i < 32 * run4) {
+          const int q = i / run4, o4 = i - q * run4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sm[q][4 * o4 + e] = tv[u][e];
+        }
+      }
+    } else {
     constexpr int U = 9;                                   // nine loads in flight per thread before the first LDS store
     for (int j0 = 0; j0 < 32 * run; j0 += 256 * U) {
       float tmp[U];
@@ -1342,6 +1367,7 @@ __global__ __launch_bounds__(256) void pack_frag_kernel(const float* __restrict_
         const int i = j0 + u * 256 + tid;
         if (i < 32 * run) { const int q = i / run; sm[q][i - q * run] = tmp[u]; }
       }
+    }
     }
     __syncthreads();
     T* dst = packed + d.dst_off + (size_t)tile * taps * 2 * 512;

@@ -299,7 +299,9 @@ class ProbabilisticUNet(nn.Module):
         self._ctx = None
         self._ctx_key = None
         self._flat = None                 # engine-bound flat fp32 parameters
-        self._engine_grads = None         # engine-written flat fp32 gradients (scratch, overwritten per call)
+        self._eg = [None, None]           # engine-written flat fp32 gradient buffers (two: p.grad may keep referencing the one written by
+        self._eg_cur = 0                  # the previous backward while the next fused call writes the other), index of the bound one,
+        self._eg_flag = [False, False]    # and whether parameters' .grad may still be views of each
         self._flat_grad = None            # what p.grad aliases (stable across calls)
         self._anchor = None
         self._step = 0
@@ -396,6 +398,46 @@ class ProbabilisticUNet(nn.Module):
     @posterior_latent_space.setter
     def posterior_latent_space(self, v):
         self._qls = v
+
+    @property
+    def _engine_grads(self):
+        return self._eg[self._eg_cur]
+
+    @_engine_grads.setter
+    def _engine_grads(self, v):
+        self._eg = [v, None]; self._eg_cur = 0; self._eg_flag = [False, False]
+
+    def _any_grad_alias(self, k):
+        buf = self._eg[k]
+        if buf is None:
+            return False
+        base = buf.data_ptr()
+        for p, off, n in self._params_in(0, self._nparams):
+            g = p.grad
+            if g is not None and g.data_ptr() == base + 4 * off:
+                return True
+        return False
+
+    def _prepare_grad_buffer(self):
+        """Before a fused backward overwrites the engine's gradient buffer: if parameters' .grad still are views of it (the reference's
+        step order is elbo -> zero_grad -> backward, so at elbo() time the previous step's gradients are still attached), switch the
+        engine to the other buffer instead of copying them out; only when both buffers are referenced (gradients kept across two
+        calls) are the current one's views moved to the stable flat buffer."""
+        cur = self._eg_cur
+        if not self._eg_flag[cur]:
+            return
+        if not self._any_grad_alias(cur):
+            self._eg_flag[cur] = False
+            return
+        other = 1 - cur
+        if self._eg[other] is None:
+            self._eg[other] = torch.zeros_like(self._eg[cur])
+        if self._eg_flag[other] and self._any_grad_alias(other):
+            self._unalias_grads()
+            return
+        self._eg_flag[other] = False
+        self._eg_cur = other
+        L.check(L.lib().pu_bind_grads(self._ctx, L.ptr(self._eg[other])), self._ctx, "pu_bind_grads")
 
     def _cfg_struct(self, H, W, max_batch, max_members):
         cfg = L.PuConfig()
@@ -580,7 +622,7 @@ class ProbabilisticUNet(nn.Module):
                     eg.mul_(gs * host_factor if gs is not None else host_factor)
             for (p, off, n), v in zip(P, self._grad_views(lo, hi, self._engine_grads)):
                 p.grad = v
-            self._grads_aliased = True
+            self._eg_flag[self._eg_cur] = True
         else:
             if host_factor != 1.0:
                 eg = eg * host_factor
@@ -596,7 +638,7 @@ class ProbabilisticUNet(nn.Module):
     def _unalias_grads(self, lo=0, hi=None):
         """Called before the engine rewrites its gradient buffer in [lo, hi): parameters whose .grad still is a view of that buffer
         (no zero_grad() since the last backward - gradient accumulation) get their gradient moved to the stable flat buffer."""
-        if not getattr(self, "_grads_aliased", False) or self._engine_grads is None:
+        if self._engine_grads is None or not self._eg_flag[self._eg_cur]:
             return
         hi = self._nparams if hi is None else hi
         base = self._engine_grads.data_ptr()
@@ -613,7 +655,7 @@ class ProbabilisticUNet(nn.Module):
                     moved = True
                 p.grad = views[i]
         if lo == 0 and hi == self._nparams:
-            self._grads_aliased = False
+            self._eg_flag[self._eg_cur] = False
 
     def _start_bucket_allreduce(self):
         """Issue one all-reduce (SUM) per gradient bucket of the fused backward on a side stream that waits for the bucket's
@@ -882,7 +924,7 @@ class ProbabilisticUNet(nn.Module):
         if with_bwd:
             self._gen["grads"] += 1
             self._finish_dp_works()                       # a previous elbo()'s collectives still own the gradient buffer
-            self._unalias_grads()                         # gradients still referenced (accumulation) leave the engine's buffer first
+            self._prepare_grad_buffer()                   # gradients still referenced keep their buffer: the engine writes the other one
         L.check(L.lib().pu_elbo_fwd_bwd(self._ctx, L.ptr(x), L.ptr(target), L.ptr(eps), B, Mx, kind,
                                         float(self.beta_0), float(self.beta_1), float(self.beta_2), float(alpha), train,
                                         self._next_seed(), with_bwd, L.ptr(scal), L.ptr(klv), L.ptr(kl2v), self._stream()),
@@ -1117,6 +1159,7 @@ class FlatAdamW:
     def zero_grad(self, set_to_none: bool = True):
         for p in self.model.parameters():
             p.grad = None
+        self.model._eg_flag = [False, False]              # nothing references the engine's gradient buffers any more
 
     @torch.no_grad()
     def step(self):

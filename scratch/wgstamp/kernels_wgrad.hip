@@ -17,9 +17,10 @@
 #include <cstdio>
 #include <cstdlib>
 
-#include "pu_kernels.h"
+#include "../../prob-unet-climate-downscaling_amd/csrc/pu_kernels.h"
 
 namespace pu {
+__device__ unsigned long long g_stamps[8];
 
 // 16 zero bytes: what an out-of-image / out-of-range staging vector is loaded from (no select after the load)
 __device__ __attribute__((aligned(16))) unsigned int g_wg_zero[4] = {0u, 0u, 0u, 0u};
@@ -184,11 +185,20 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad16_kernel(WgradArgs a) {
 
   int tile = blockIdx.x;
   int cur = 0;
+  unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
+  auto stamp = [&]() -> unsigned long long { unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) :: "memory"); return t; };
   if (tile < ntiles) { gload(tile); lstore(0); }
   __syncthreads();
+  const unsigned long long tk0 = stamp();
   for (; tile < ntiles; tile += gridDim.x) {
     const int nxt = tile + gridDim.x;
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long t0 = stamp();
+    __builtin_amdgcn_sched_barrier(0);
     if (nxt < ntiles) gload(nxt);
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long t1 = stamp();
+    __builtin_amdgcn_sched_barrier(0);
     // lane-constant fragment bases of this tile's buffer; a K-step adds a compile-time offset (pixel kk * 16 + lq of the tile is pixel lq
     // shifted by whole rows / a multiple of 16 columns: (kk * 16 + lq) % TW == kk * 16 % TW + lq for every tile shape used here)
     const uint16_t* bufp = lds + cur * BUF;
@@ -221,6 +231,9 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad16_kernel(WgradArgs a) {
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long t2 = stamp();
+    __builtin_amdgcn_sched_barrier(0);
     if (do_bias) {
       const int bc = tid % BCO, bp = tid / BCO;
       const uint16_t* col = lds + cur * BUF + ((bc >> 5) * BM) * 32 + (bc & 31);
@@ -230,10 +243,27 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad16_kernel(WgradArgs a) {
         bsum += ET<T>::ld(&v);
       }
     }
-    if (nxt < ntiles) lstore(cur ^ 1);          // (the next tile's vectors in one burst after the K-steps; spreading them between the MFMA
-                                                //  groups of the last K-steps measured neutral to 5 % slower, profiles/r2_ab_runs.txt)
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long t3 = stamp();
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long t3b = stamp();
+    __builtin_amdgcn_sched_barrier(0);
+    if (nxt < ntiles) lstore(cur ^ 1);
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long t4 = stamp();
+    __builtin_amdgcn_sched_barrier(0);
     __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long t5 = stamp();
+    ph[0] += t1 - t0; ph[1] += t2 - t1; ph[2] += t3 - t2; ph[3] += t3b - t3; ph[4] += t4 - t3b; ph[5] += t5 - t4;
     cur ^= 1;
+  }
+  if (l == 0) {
+    for (int i = 0; i < 6; ++i) atomicAdd(&g_stamps[i], ph[i]);
+    atomicAdd(&g_stamps[6], stamp() - tk0);
+    atomicAdd(&g_stamps[7], 1ull);
   }
   if (do_bias) {                                  // combine the pixel parts, one partial row per split
     float* red = reinterpret_cast<float*>(smem_raw);
@@ -507,3 +537,10 @@ template hipError_t launch_wgrad16_main<f16>(const WgradArgs&, hipStream_t, Wgra
 template hipError_t launch_wgrad16_main<bf16>(const WgradArgs&, hipStream_t, WgradReduce*);
 
 }  // namespace pu
+extern "C" __attribute__((visibility("default"))) int pu_debug_stamps(unsigned long long* out) {
+  hipDeviceSynchronize();
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(pu::g_stamps), 64);
+  unsigned long long z[8] = {0,0,0,0,0,0,0,0};
+  hipMemcpyToSymbol(HIP_SYMBOL(pu::g_stamps), z, 64);
+  return 0;
+}
