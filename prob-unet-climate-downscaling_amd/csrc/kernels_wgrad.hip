@@ -51,8 +51,13 @@ __device__ __forceinline__ Frag tr_frag(const uint16_t* p0, const uint16_t* p1) 
 }
 
 // BCO = couts per block (64, or 32 for the Cout <= 32 layers of the 256 x 256 level: half of a 64-cout tile would be zero padding)
+// resident blocks per CU the register allocation is held to: the 4-wave forms run two blocks per CU (three for the 32 x 32 tile of the
+// 256 x 256 level) - the interleaved K loop would otherwise take 264-284 registers and halve that
+constexpr int wg16_min_blocks(int TH, int TW, int BCI, int NW, int BCO) {
+  return NW != 4 || TH * TW < 128 || (BCI == 64 && BCO == 64) ? 1 : (BCI == 32 && BCO == 32 ? 3 : 2);
+}
 template <typename T, int KS, int TH, int TW, int BCI, int NW, int BCO>
-__global__ __launch_bounds__(64 * NW) void conv_wgrad16_kernel(WgradArgs a) {
+__global__ __launch_bounds__(64 * NW, wg16_min_blocks(TH, TW, BCI, NW, BCO)) void conv_wgrad16_kernel(WgradArgs a) {
   typedef MMW<T> M;
   constexpr int NTH = 64 * NW;
   constexpr int TAPS = KS * KS, PADP = KS / 2;
@@ -153,7 +158,7 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad16_kernel(WgradArgs a) {
       if (tid + k * NTH < NVA_TOT) *reinterpret_cast<V16*>(sb + loff_a[k]) = ra[k];
     }
   };
-  constexpr int NPARTS = NVD + NVA, STEPS = BM / 16;
+  constexpr int NPARTS = NVD + NVA;
   auto lstore = [&](int buf) {
 #pragma unroll
     for (int p = 0; p < NPARTS; ++p) lstore_part(buf, p);
@@ -206,18 +211,24 @@ __global__ __launch_bounds__(64 * NW) void conv_wgrad16_kernel(WgradArgs a) {
 #pragma unroll
       for (int j = 0; j < NJ; ++j) fb[slot][j] = tr_frag<typename M::Frag>(pA0[j] + da, pA1[j] + da);
     };
-    load_step(0, 0);
+    // MFMAs of step kk and the transposed reads of step kk+1 are issued INTERLEAVED (one MFMA, then its share of the reads, under that
+    // MFMA's 32 pipe cycles): a wave issues in order, so a block of 12 reads between two blocks of MFMAs leaves the matrix pipe idle
+    // for the ~100 cycles the reads take to issue whenever the SIMD's other wave is not multiplying at that moment.
+    // A tap group beyond the last tap (1 x 1 layers: second group) skips the K loop and only helps with the staging.
+    if (grp_live) {
+      constexpr int NRD = 2 + 2 * NJ, RPM = (NRD + NJ - 1) / NJ;
+      load_step(0, 0);
 #pragma unroll
-    for (int kk = 0; kk < BM / 16; ++kk) {
-      if (kk + 1 < BM / 16) load_step(kk + 1, (kk + 1) & 1);
-      __builtin_amdgcn_sched_barrier(0);
-      // every wave multiplies all NJ slots: a slot beyond the last tap (the second tap group of 9 = 5 + 4) re-reads tap 0 and its result is
-      // never stored.  The guard `if (tap0 + j < TAPS)` that used to sit here depends on the wave index, which the compiler treats as
-      // divergent: each MFMA ended up in its own exec-masked basic block behind a branch pair (40 per tile and wave) - the reason this
-      // kernel sat at 28 % MFMA utilisation with its waves marching through load / multiply phases together.
-      if (grp_live) {
+      for (int kk = 0; kk < BM / 16; ++kk) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (kk + 1 < BM / 16) load_step(kk + 1, (kk + 1) & 1);
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[j] = M::mfma(fa[kk & 1], fb[kk & 1][j], acc[j]);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);            // one MFMA
+          __builtin_amdgcn_sched_group_barrier(0x100, RPM, 0);          // its share of the next step's LDS reads
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
