@@ -616,12 +616,22 @@ __global__ __launch_bounds__(64 * WM * WN, (MS == 16 && TH * TW / WM <= 128) ? 2
 #pragma unroll
           for (int j = 0; j < NTM; ++j) fb[(g + 1) & 1][j] = *reinterpret_cast<const typename M::Frag*>(sb + pbase[ph1 * NTM + j] + toff1);
         }
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
           for (int j = 0; j < NTM; ++j) acc4[h][ph * NTM + j] = M::mfma16(fa[t][h], fb[g & 1][j], acc4[h][ph * NTM + j]);
         if (ph == 1) { fa[t][0] = wload(cn, t, 0); fa[t][1] = wload(cn, t, 1); }
+        // issue order inside the group: one LDS read of group g+1 behind each of the first NTM MFMAs (a wave issues in order - a block
+        // of reads between two blocks of MFMAs is ~8 idle pipe cycles per read whenever the SIMD's other wave is not multiplying),
+        // the rest of the MFMAs, then the weight refills
+        if (g + 1 < 2 * TAPS) {
+#pragma unroll
+          for (int j = 0; j < NTM; ++j) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); }
+          __builtin_amdgcn_sched_group_barrier(0x008, NTM, 0);
+        } else {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2 * NTM, 0);
+        }
+        if (ph == 1) __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
     } else {

@@ -15,6 +15,7 @@
 //   * each block writes its fp32 partial tile to a slab [split][tap][cout][cin] with coalesced stores; a second kernel
 //     sums the slabs in a fixed order (bitwise reproducible, no float atomics) and adds into the fp32 gradient
 #include <cstdio>
+#include <type_traits>
 #include <cstdlib>
 
 #include "pu_kernels.h"
@@ -73,7 +74,8 @@ __global__ __launch_bounds__(64 * NW, wg16_min_blocks(TH, TW, BCI, NW, BCO)) voi
   // SIMD hide each other's LDS waits in the 8-wave forms; a group beyond the last tap only helps with the staging loads)
   constexpr int GROUPS = NW / (COS * CIS);
   constexpr int NJ = (TAPS + GROUPS - 1) / GROUPS;
-  static_assert(NW % (COS * CIS) == 0 && GROUPS >= 1, "wave roles");
+  static_assert(NW % (COS * CIS) == 0 && GROUPS >= 1 && GROUPS <= 4, "wave roles");
+  constexpr bool PHASED = NW == 8 && GROUPS == 2;      // the two tap groups alternate between multiplying and staging (see the tile loop)
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   uint16_t* lds = reinterpret_cast<uint16_t*>(smem_raw);
@@ -82,9 +84,6 @@ __global__ __launch_bounds__(64 * NW, wg16_min_blocks(TH, TW, BCI, NW, BCO)) voi
   const int ct = wave % COS;
   const int it = (wave / COS) % CIS;
   const int tap0 = (wave / (COS * CIS)) * NJ;
-  // a tap group entirely beyond the last tap (the fourth group of 9 = 3 + 3 + 3) only helps with the staging; readfirstlane makes the
-  // test a scalar branch (one per K-step) instead of exec-mask juggling around every MFMA
-  const bool grp_live = __builtin_amdgcn_readfirstlane(tap0) < TAPS;
   const int co0 = blockIdx.y * BCO, ci0 = blockIdx.z * BCI;
   const int tiles_x = a.W / TW, tiles_y = a.H / TH;
   const int ntiles = tiles_x * tiles_y * a.B;
@@ -97,7 +96,8 @@ __global__ __launch_bounds__(64 * NW, wg16_min_blocks(TH, TW, BCI, NW, BCO)) voi
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-  V16 rd[NVD], ra[NVA];
+  typedef int wg_i32x4 __attribute__((ext_vector_type(4)));   // (whole-vector values: the {w[4]} struct form was split into scalars and re-joined
+  wg_i32x4 rd[NVD], ra[NVA];                                   //  with v_mov copies behind an s_waitcnt vmcnt right after the loads)
   // Tile-invariant staging plan of this thread (the loop is instruction-issue bound: SQ_ACTIVE_INST_ANY 45 % of the wave cycles at two
   // waves per SIMD, MFMA pipe 28 % busy - every integer instruction removed from the tile loop is time given to the matrix pipe):
   //   goff_d / goff_a: element offset of the vector relative to the tile's first pixel, 32-bit (pu_create bounds the tensors);
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(64 * NW, wg16_min_blocks(TH, TW, BCI, NW, BCO)) voi
   }
   static_assert(NVD <= 16 && NVA <= 16, "staging plan bit fields");
   const ptrdiff_t zoff_d = reinterpret_cast<const uint16_t*>(g_wg_zero) - dy, zoff_a = reinterpret_cast<const uint16_t*>(g_wg_zero) - in;
-  auto gload = [&](int tile) {
+  auto gload = [&](int tile) __attribute__((always_inline)) {
     int pt = tile;
     const int tx0 = (pt % tiles_x) * TW; pt /= tiles_x;
     const int ty0 = (pt % tiles_y) * TH; pt /= tiles_y;
@@ -138,28 +138,26 @@ __global__ __launch_bounds__(64 * NW, wg16_min_blocks(TH, TW, BCI, NW, BCO)) voi
 #pragma unroll
     for (int k = 0; k < NVD; ++k) {
       const bool ok = (vmask >> k) & 1u;
-      const V16 v = *reinterpret_cast<const V16*>(dy + (ok ? (ptrdiff_t)(dbase + (unsigned)goff_d[k]) : zoff_d));
-      rd[k].w[0] = v.w[0]; rd[k].w[1] = v.w[1]; rd[k].w[2] = v.w[2]; rd[k].w[3] = v.w[3];
+      rd[k] = *reinterpret_cast<const wg_i32x4*>(dy + (ok ? (ptrdiff_t)(dbase + (unsigned)goff_d[k]) : zoff_d));
     }
 #pragma unroll
     for (int k = 0; k < NVA; ++k) {
       const bool ok = ((vmask >> (16 + k)) & 1u) && (((unsigned)(aedge >> (4 * k)) & omask) == 0);
-      const V16 v = *reinterpret_cast<const V16*>(in + (ok ? (ptrdiff_t)(abase + (unsigned)goff_a[k]) : zoff_a));
-      ra[k].w[0] = v.w[0]; ra[k].w[1] = v.w[1]; ra[k].w[2] = v.w[2]; ra[k].w[3] = v.w[3];
+      ra[k] = *reinterpret_cast<const wg_i32x4*>(in + (ok ? (ptrdiff_t)(abase + (unsigned)goff_a[k]) : zoff_a));
     }
   };
   // one staged vector -> LDS: part p < NVD is a dy vector, the rest are halo-tile vectors (slots beyond the tile write nothing)
-  auto lstore_part = [&](int buf, int p) {
+  auto lstore_part = [&](int buf, int p) __attribute__((always_inline)) {
     uint16_t* sb = lds + buf * BUF;
     if (p < NVD) {
-      if (tid + p * NTH < NVD_TOT) *reinterpret_cast<V16*>(sb + loff_d[p]) = rd[p];
+      if (tid + p * NTH < NVD_TOT) *reinterpret_cast<wg_i32x4*>(sb + loff_d[p]) = rd[p];
     } else {
       const int k = p - NVD;
-      if (tid + k * NTH < NVA_TOT) *reinterpret_cast<V16*>(sb + loff_a[k]) = ra[k];
+      if (tid + k * NTH < NVA_TOT) *reinterpret_cast<wg_i32x4*>(sb + loff_a[k]) = ra[k];
     }
   };
   constexpr int NPARTS = NVD + NVA;
-  auto lstore = [&](int buf) {
+  auto lstore = [&](int buf) __attribute__((always_inline)) {
 #pragma unroll
     for (int p = 0; p < NPARTS; ++p) lstore_part(buf, p);
   };
@@ -189,48 +187,47 @@ __global__ __launch_bounds__(64 * NW, wg16_min_blocks(TH, TW, BCI, NW, BCO)) voi
 
   int tile = blockIdx.x;
   int cur = 0;
-  if (tile < ntiles) { gload(tile); lstore(0); }
-  __syncthreads();
-  for (; tile < ntiles; tile += gridDim.x) {
-    const int nxt = tile + gridDim.x;
-    if (nxt < ntiles) gload(nxt);
+  // the MFMA part of one tile out of LDS buffer `cur`, NV = taps this wave really owns (+ its share of the fused bias column sums)
+  auto ktile = [&](int cur, auto nv, bool live) __attribute__((always_inline)) {
+    constexpr int NV = decltype(nv)::value;
     // lane-constant fragment bases of this tile's buffer; a K-step adds a compile-time offset (pixel kk * 16 + lq of the tile is pixel lq
     // shifted by whole rows / a multiple of 16 columns: (kk * 16 + lq) % TW == kk * 16 % TW + lq for every tile shape used here)
     const uint16_t* bufp = lds + cur * BUF;
     const uint16_t* pD0 = bufp + lane_d0; const uint16_t* pD1 = bufp + lane_d1;
-    const uint16_t* pA0[NJ]; const uint16_t* pA1[NJ];
+    const uint16_t* pA0[NV > 0 ? NV : 1]; const uint16_t* pA1[NV > 0 ? NV : 1];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) { pA0[j] = bufp + lane_a0[j]; pA1[j] = bufp + lane_a1[j]; }
-    // software-pipelined over the K-steps: the transposed reads of step kk+1 are issued as one block before the MFMAs of step
-    // kk (sched_barrier keeps the blocks apart), so they land under those MFMAs instead of stalling their own consumers
-    typename M::Frag fa[2], fb[2][NJ];
-    auto load_step = [&](int kk, int slot) {
-      const int dd = kk * 16 * 32;                                                        // dy tile: pixel rows of 32 elements
-      const int da = (TW >= 16 ? ((kk * 16 / TW) * IW + (kk * 16 % TW)) : (kk * 16 / TW) * IW) * 32;   // halo tile
-      fa[slot] = tr_frag<typename M::Frag>(pD0 + dd, pD1 + dd);
+    for (int j = 0; j < NV; ++j) { pA0[j] = bufp + lane_a0[j]; pA1[j] = bufp + lane_a1[j]; }
+    if constexpr (NV > 0) {
+      // software-pipelined over the K-steps: the transposed reads of step kk+1 are issued as one block before the MFMAs of step
+      // kk (sched_barrier keeps the blocks apart), so they land under those MFMAs instead of stalling their own consumers
+      typename M::Frag fa[2], fb[2][NV];
+      auto load_step = [&](int kk, int slot) __attribute__((always_inline)) {
+        const int dd = kk * 16 * 32;                                                        // dy tile: pixel rows of 32 elements
+        const int da = (TW >= 16 ? ((kk * 16 / TW) * IW + (kk * 16 % TW)) : (kk * 16 / TW) * IW) * 32;   // halo tile
+        fa[slot] = tr_frag<typename M::Frag>(pD0 + dd, pD1 + dd);
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) fb[slot][j] = tr_frag<typename M::Frag>(pA0[j] + da, pA1[j] + da);
-    };
-    // MFMAs of step kk and the transposed reads of step kk+1 are issued INTERLEAVED (one MFMA, then its share of the reads, under that
-    // MFMA's 32 pipe cycles): a wave issues in order, so a block of 12 reads between two blocks of MFMAs leaves the matrix pipe idle
-    // for the ~100 cycles the reads take to issue whenever the SIMD's other wave is not multiplying at that moment.
-    // A tap group beyond the last tap (1 x 1 layers: second group) skips the K loop and only helps with the staging.
-    if (grp_live) {
-      constexpr int NRD = 2 + 2 * NJ, RPM = (NRD + NJ - 1) / NJ;
-      load_step(0, 0);
+        for (int j = 0; j < NV; ++j) fb[slot][j] = tr_frag<typename M::Frag>(pA0[j] + da, pA1[j] + da);
+      };
+      // MFMAs of step kk and the transposed reads of step kk+1 are issued INTERLEAVED (one MFMA, then its share of the reads, under that
+      // MFMA's 32 pipe cycles): a wave issues in order, so a block of 12 reads between two blocks of MFMAs leaves the matrix pipe idle
+      // for the ~100 cycles the reads take to issue whenever the SIMD's other wave is not multiplying at that moment.
+      if (live) {                                 // (scalar: a tap group entirely beyond the last tap only helps with the staging)
+        constexpr int NRD = 2 + 2 * NV, RPM = (NRD + NV - 1) / NV;
+        load_step(0, 0);
 #pragma unroll
-      for (int kk = 0; kk < BM / 16; ++kk) {
-        __builtin_amdgcn_sched_barrier(0);
-        if (kk + 1 < BM / 16) load_step(kk + 1, (kk + 1) & 1);
+        for (int kk = 0; kk < BM / 16; ++kk) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (kk + 1 < BM / 16) load_step(kk + 1, (kk + 1) & 1);
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) acc[j] = M::mfma(fa[kk & 1], fb[kk & 1][j], acc[j]);
+          for (int j = 0; j < NV; ++j) acc[j] = M::mfma(fa[kk & 1], fb[kk & 1][j], acc[j]);
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);            // one MFMA
-          __builtin_amdgcn_sched_group_barrier(0x100, RPM, 0);          // its share of the next step's LDS reads
+          for (int j = 0; j < NV; ++j) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);            // one MFMA
+            __builtin_amdgcn_sched_group_barrier(0x100, RPM, 0);          // its share of the next step's LDS reads
+          }
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
-      __builtin_amdgcn_sched_barrier(0);
     }
     if (do_bias) {
       const int bc = tid % BCO, bp = tid / BCO;
@@ -241,10 +238,66 @@ __global__ __launch_bounds__(64 * NW, wg16_min_blocks(TH, TW, BCI, NW, BCO)) voi
         bsum += ET<T>::ld(&v);
       }
     }
-    if (nxt < ntiles) lstore(cur ^ 1);          // (the next tile's vectors in one burst after the K-steps; spreading them between the MFMA
-                                                //  groups of the last K-steps measured neutral to 5 % slower, profiles/r2_ab_runs.txt)
+  };
+  // taps of this wave's group (the guard `if (tap0 + j < TAPS)` that used to sit on every MFMA depends on the wave index, which the
+  // compiler treats as divergent: each MFMA ended up in its own exec-masked basic block; the group is now picked once, by a scalar branch)
+  const int grp = __builtin_amdgcn_readfirstlane(wave / (COS * CIS));
+  auto ktile_grp = [&](int cur) __attribute__((always_inline)) {
+    if constexpr (PHASED) {                       // two groups: exact tap counts (9 = 5 + 4), one instantiation each
+      if (grp == 0) ktile(cur, std::integral_constant<int, (NJ < TAPS ? NJ : TAPS)>{}, true);
+      else ktile(cur, std::integral_constant<int, (TAPS - NJ > 0 ? TAPS - NJ : 0)>{}, true);
+    } else {
+      // one instantiation (register allocation as before): every live group multiplies all NJ slots - a slot beyond the last tap
+      // re-reads tap 0 and its result is never stored; a group entirely beyond the last tap (the fourth group of 9 = 3 + 3 + 3)
+      // only helps with the staging
+      ktile(cur, std::integral_constant<int, NJ>{}, grp * NJ < TAPS);
+    }
+  };
+  const int G = gridDim.x;
+  if constexpr (PHASED) {
+    // Two tap groups = the two waves of every SIMD.  Stamps of the one-phase loop (all eight waves: load burst -> K-steps -> LDS stores
+    // -> barrier) showed the matrix pipe busy only during the K-steps, about half of each tile: 17 % of the wave cycles went into
+    // ISSUING the load burst (64 KB through the CU's 64-byte-per-clock vector memory path while nobody multiplies), 7 % into the LDS
+    // stores, 22 % into the barrier.  Here the groups alternate: while group A multiplies tile t, group B writes its staged vectors of
+    // tile t + 1 to the other LDS buffer and issues its loads of tile t + 2, and vice versa; two barriers per tile, every SIMD always
+    // has one wave in its MFMA phase, and a load has a whole tile to arrive.
+    if (tile < ntiles) { gload(tile); lstore(0); }
+    if (tile + G < ntiles) gload(tile + G);
     __syncthreads();
-    cur ^= 1;
+    // (two separate loops - one per group, same barrier count - rather than `if (grp == 0) multiply else stage` twice inside one
+    //  loop: with the branches inside the loop the register allocator put the staged vectors and the MFMA fragments of the two
+    //  branches on the same registers and copied the loaded vectors away behind an s_waitcnt vmcnt right after issuing the loads)
+    if (grp == 0) {
+      for (; tile < ntiles; tile += G) {
+        ktile_grp(cur);
+        __syncthreads();
+        if (tile + G < ntiles) lstore(cur ^ 1);
+        if (tile + 2 * G < ntiles) gload(tile + 2 * G);
+        __syncthreads();
+        cur ^= 1;
+      }
+    } else {
+      for (; tile < ntiles; tile += G) {
+        if (tile + G < ntiles) lstore(cur ^ 1);
+        if (tile + 2 * G < ntiles) gload(tile + 2 * G);
+        __syncthreads();
+        ktile_grp(cur);
+        __syncthreads();
+        cur ^= 1;
+      }
+    }
+  } else {
+    if (tile < ntiles) { gload(tile); lstore(0); }
+    __syncthreads();
+    for (; tile < ntiles; tile += G) {
+      const int nxt = tile + G;
+      if (nxt < ntiles) gload(nxt);
+      ktile_grp(cur);
+      if (nxt < ntiles) lstore(cur ^ 1);          // (the next tile's vectors in one burst after the K-steps; spreading them between the MFMA
+                                                  //  groups of the last K-steps measured neutral to 5 % slower, profiles/r2_ab_runs.txt)
+      __syncthreads();
+      cur ^= 1;
+    }
   }
   if (do_bias) {                                  // combine the pixel parts, one partial row per split
     float* red = reinterpret_cast<float*>(smem_raw);
