@@ -468,7 +468,8 @@ static int conv_fwd(pu_ctx* c, const ConvL& L, TV in, TV out, int B, bool relu, 
 // dx (+)= dgrad(dy)
 struct GnbReq { const GNL* n = nullptr; TV x; int train = 0; uint64_t seed = 0; int slots = 0; };   // in: the GroupNorm whose dy this data gradient is; out: slots
 template <typename T>
-static int conv_dgrad(pu_ctx* c, const ConvL& L, TV dy, TV dx, int B, int accumulate, hipStream_t s, GnbReq* gq = nullptr) {
+static int conv_dgrad(pu_ctx* c, const ConvL& L, TV dy, TV dx, int B, int accumulate, hipStream_t s, GnbReq* gq = nullptr,
+                      const TV* relu_mask = nullptr) {
   ConvArgs a; memset(&a, 0, sizeof a);
   if (gq) gq->slots = 0;
   if (gq && gq->n && gq->n->fuse_bwd && c->gn_rows && !accumulate && dx.H > 0) {
@@ -483,6 +484,7 @@ static int conv_dgrad(pu_ctx* c, const ConvL& L, TV dy, TV dx, int B, int accumu
   a.in = dy.p; a.in_ld = dy.ld; a.Cin = L.cout;
   a.wpk = (char*)c->packed + (size_t)L.pk_bwd * c->esz; a.cin_pk = L.cout_pk; a.cout_pk = L.rows_bwd; a.taps = L.ks * L.ks;
   a.bias = nullptr; a.res = nullptr;
+  if (relu_mask) { a.relu_mask = relu_mask->p; a.relu_mask_ld = relu_mask->ld; }
   a.out = dx.p; a.out_ld = dx.ld;
   a.Cout = dx.C;                      // write every allocated plane (planes >= L.cin receive zeros from zero-padded weights)
   if (a.Cout > L.rows_bwd) a.Cout = L.rows_bwd;
@@ -778,15 +780,22 @@ static int gauss_backward(pu_ctx* c, GaussNet& g, hipStream_t s) {
   TV lastg = with_b(g.outs.back().g, B);
   CKH(launch_heads_bwd<T>(with_b(g.outs.back().v, B), lastg, g.hbuf, P(c, g.wmu), P(c, g.wls), g.dmu, g.dls, L,
                           G(c, g.wmu), G(c, g.bmu), G(c, g.wls), G(c, g.bls), c->inv_scale, s, inv_dev));
+  static const bool no_mask_fuse = getenv("PU_NO_RELU_MASK_FUSE") != nullptr;      // diagnostic: every ReLU backward as its own pass
+  bool masked_by_dgrad = false;
   for (int i = (int)g.convs.size() - 1; i >= 0; --i) {
     TV dy = with_b(g.outs[i].g, B);
     // ReLU backward of this layer's output: folded into the max-pool backward that produced dy when a pool follows the layer
     // (networks: conv -> ReLU -> pool; the routed gradient is dropped where the window maximum is not positive), else its own pass
+    // ... or into the data gradient of the layer above, which wrote dy (no pool in between: ins[i + 1] aliases outs[i])
     const bool masked_by_pool = i + 1 < (int)g.convs.size() && g.pool_before[i + 1];
-    if (!masked_by_pool) CKH(launch_relu_bwd<T>(with_b(g.outs[i].v, B), dy, s));
+    if (!masked_by_pool && !masked_by_dgrad) CKH(launch_relu_bwd<T>(with_b(g.outs[i].v, B), dy, s));
+    masked_by_dgrad = false;
     if ((r = conv_wgrad<T>(c, g.convs[i], g.outs[i].g, g.ins[i].v, B, s, G(c, g.convs[i].b_off), nullptr, inv_dev))) return r;
     if (i == 0) break;
-    if ((r = conv_dgrad<T>(c, g.convs[i], g.outs[i].g, g.ins[i].g, B, 0, s))) return r;
+    const bool fuse_mask = !g.pool_before[i] && g.convs[i].frag && !no_mask_fuse;
+    const TV mask = with_b(g.outs[i - 1].v, B);
+    if ((r = conv_dgrad<T>(c, g.convs[i], g.outs[i].g, g.ins[i].g, B, 0, s, nullptr, fuse_mask ? &mask : nullptr))) return r;
+    masked_by_dgrad = fuse_mask;
     if (g.pool_before[i]) CKH(launch_maxpool_bwd<T>(with_b(g.outs[i - 1].v, B), with_b(g.ins[i].g, B), with_b(g.outs[i - 1].g, B), s, true));
     // else ins[i] aliases outs[i-1] (same Act): gradient already in place
   }
@@ -870,8 +879,10 @@ int pu_create(const pu_config* cfg, int device, pu_ctx** out) {
     // communication stream while the rest of the backward is still being computed - yields to the compute kernels at dispatch
     int prio_least = 0, prio_greatest = 0;
     if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess) { prio_least = prio_greatest = 0; (void)hipGetLastError(); }
-    if (hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, prio_greatest) != hipSuccess) { c->side = nullptr; (void)hipGetLastError(); }
-    if (hipStreamCreateWithPriority(&c->side2, hipStreamNonBlocking, prio_greatest) != hipSuccess) { c->side2 = nullptr; (void)hipGetLastError(); }
+    int prio = prio_greatest;
+    if (const char* sp = getenv("PU_SIDE_PRIO")) prio = sp[0] == 'l' ? prio_least : sp[0] == 'n' ? 0 : prio_greatest;   // diagnostic: low / normal / high
+    if (hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, prio) != hipSuccess) { c->side = nullptr; (void)hipGetLastError(); }
+    if (hipStreamCreateWithPriority(&c->side2, hipStreamNonBlocking, prio) != hipSuccess) { c->side2 = nullptr; (void)hipGetLastError(); }
   }
 
   if (c->side) {

@@ -342,7 +342,7 @@ static inline void stat_resolve(ConvArgs& a, int slots) {
 static inline void gnb_resolve(ConvArgs& a, int slots) {
   if (a.gnb.slots) *a.gnb.slots = 0;
   if (!a.gnb.x) return;
-  if (slots > a.gnb.cap || a.bias || a.res || a.relu || a.accumulate || a.stat_out || !a.gnb.part || !a.gnb.coef || a.gnb.C != a.Cout) { a.gnb.x = nullptr; return; }
+  if (slots > a.gnb.cap || a.bias || a.res || a.relu_mask || a.relu || a.accumulate || a.stat_out || !a.gnb.part || !a.gnb.coef || a.gnb.C != a.Cout) { a.gnb.x = nullptr; return; }
   if (a.gnb.slots) *a.gnb.slots = slots;
 }
 
@@ -430,7 +430,28 @@ __device__ __forceinline__ void conv3_epilogue_store(const ConvArgs& a, const T*
     wave_stat_store(s1, s2, l, a.gnb.part + (((size_t)b * slots + slot) * a.Cout + co) * 2, okc);
     return;
   }
-  const bool mod = res != nullptr || a.accumulate || a.relu;      // (wave-uniform)
+  const T* mk = reinterpret_cast<const T*>(a.relu_mask);
+  if (mk && !res && !a.accumulate && !a.relu && !a.stat_out) {
+    // ---- data gradient of a conv -> ReLU chain: the ReLU backward of the layer below (its saved output is the mask), every mask vector in
+    //      flight before the first use
+    if (okc) {
+      V16 mr[NIT];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) mr[it] = *reinterpret_cast<const V16*>(mk + (size_t)((pixbase + lpix[it]) * (unsigned)a.relu_mask_ld + co));
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int pw = (it * 64 + l) >> 2;
+        float v[8], m[8];
+        unpack<T>(*reinterpret_cast<const V16*>(stage + pw * ERS + ch * 8), v);
+        unpack<T>(mr[it], m);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = m[e] > 0.f ? v[e] : 0.f;
+        *reinterpret_cast<V16*>(out + (size_t)((pixbase + lpix[it]) * (unsigned)a.out_ld + co)) = pack<T>(v);
+      }
+    }
+    return;
+  }
+  const bool mod = res != nullptr || a.accumulate || a.relu || mk != nullptr;      // (wave-uniform)
   if (okc) {
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -455,6 +476,11 @@ __device__ __forceinline__ void conv3_epilogue_store(const ConvArgs& a, const T*
         if (a.relu) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : 0.f;
+        }
+        if (mk) {
+          float m[8]; unpack<T>(*reinterpret_cast<const V16*>(mk + (size_t)(pix * (unsigned)a.relu_mask_ld + co)), m);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = m[e] > 0.f ? v[e] : 0.f;
         }
         pk = pack<T>(v);
         if (a.stat_out) unpack<T>(pk, v);                         // statistics of the values as stored (rounded to T)
@@ -1086,6 +1112,7 @@ hipError_t launch_conv(const ConvArgs& a, hipStream_t s) {
     if (a.taps == 1) return launch_conv3<T, 1>(a, s);
     return hipErrorInvalidValue;
   }
+  if (a.relu_mask) return hipErrorInvalidValue;     // only the conv3 / conv3p epilogue applies a ReLU mask (conv_uses_frag_layout())
   if (a.taps == 9) return launch_ks<T, 3>(a, s);
   if (a.taps == 1) return launch_ks<T, 1>(a, s);
   return hipErrorInvalidValue;

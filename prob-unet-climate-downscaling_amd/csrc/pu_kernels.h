@@ -51,6 +51,8 @@ struct ConvArgs {
   const void* wpk; int cin_pk; int cout_pk; int taps;   // packed weights [cout_pk][taps][cin_pk]
   const float* bias;                             // fp32 [Cout] or null
   const void* res; int res_ld;                   // residual (same shape as out) or null
+  const void* relu_mask; int relu_mask_ld;       // optional (conv3 / conv3p only): out = mask > 0 ? value : 0 - the ReLU backward of the layer
+                                                 // whose output `relu_mask` is, folded into the data gradient that produces its gradient
   void* out; int out_ld; int Cout;
   int B, H, W;
   int relu; int accumulate;
