@@ -153,10 +153,10 @@ def cpu_baseline(cfg, seconds_budget=25.0):
 
 
 def pmc_traffic(kernel_tag):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/r2_pmc_traffic.json:
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/r3_pmc_traffic.json:
     FETCH_SIZE x 2 (gfx950 correction, MI355X_MICROARCH.md §HBM) + WRITE_SIZE, KiB -> bytes).  None if not collected."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r3_pmc_traffic.json")) as f:
             t = json.load(f)
         return t.get(kernel_tag, {}).get("hbm_bytes_per_launch")
     except Exception:
@@ -431,7 +431,7 @@ def main():
             peak = PEAK[args.dtype] / 1e12
             roofline = dict(bound="mfma", kernel=d["name"], achieved=round(achieved, 2), peak=peak, unit="TFLOP/s",
                             frac=round(achieved / peak, 4), traffic=pmc_traffic(d["name"]),
-                            traffic_source="profiles/r2_pmc_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this "
+                            traffic_source="profiles/r3_pmc_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this "
                                            "command, committed; not collected in this run)",
                             timing_source=f"HIP events on the kernel's launch stream, this run, side streams off, mean of {NPROF} steps",
                             kernel_function_ms_per_step={k: round(v, 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1])},

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(64 * NW, wg16_min_blocks(TH, TW, BCI, NW, BCO)) voi
   constexpr int GROUPS = NW / (COS * CIS);
   constexpr int NJ = (TAPS + GROUPS - 1) / GROUPS;
   static_assert(NW % (COS * CIS) == 0 && GROUPS >= 1 && GROUPS <= 4, "wave roles");
-  constexpr bool PHASED = NW == 8 && GROUPS == 2;      // the two tap groups alternate between multiplying and staging (see the tile loop)
+  constexpr bool PHASED = NW == 8 && GROUPS == 2 && TAPS > NJ;   // both tap groups own taps: they alternate between multiplying and staging (tile loop)
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   uint16_t* lds = reinterpret_cast<uint16_t*>(smem_raw);

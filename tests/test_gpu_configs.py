@@ -211,3 +211,41 @@ def test_create_rejects_plans_beyond_the_32_bit_pixel_offset_range():
     cfg = m._cfg_struct(256, 256, 683, 1)
     rc = L_.lib().pu_create(C.byref(cfg), 0, C.byref(ctx))
     assert rc == -1 and b"2^32" in L_.lib().pu_last_error(None)
+
+
+_MASK_SCRIPT = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[1])
+import probunet_amd as pa
+from oracle import probunet_oracle as O
+from tests.helpers import random_params
+args = (4, 1, 6, [32, 64, 128], 32, [1, 2, 4])
+P = random_params(O.Config(*args), 3)
+g = torch.Generator().manual_seed(11)
+x = torch.randn(2, 4, 64, 64, generator=g); y = torch.randn(2, 1, 64, 64, generator=g); eps = torch.randn(2, 2, 6, generator=g)
+m = pa.ProbabilisticUNet(*args, 0.7, 1.3, 0.0, dtype="f16", init=False, max_batch=2, max_members=2)
+m.load_state_dict(P); m = m.to("cuda:0").train(); m.dropout = 0.0
+total = m.elbo(x.cuda(), y.cuda(), None, M=2, eps=eps.cuda())[0]
+total.backward(); torch.cuda.synchronize()
+torch.save({k: p.grad.detach().cpu() for k, p in m.named_parameters() if k.startswith(("prior", "posterior"))}, sys.argv[2])
+"""
+
+
+def test_relu_backward_folded_into_the_data_gradient_is_bit_identical_to_its_own_pass(tmp_path):
+    """Latent encoders (conv -> ReLU chains, src/prob_unet.py:60-105): the f16 engine folds each ReLU backward into the epilogue of
+    the data gradient above it (ConvArgs::relu_mask).  Zeroing before or after the rounding to f16 is the same value, so the encoder
+    gradients must equal those of the build that runs every ReLU backward as its own pass (PU_NO_RELU_MASK_FUSE=1) bit for bit.
+    Two child processes, one after the other (the switch is read once per process)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for tag, env in (("fused", {}), ("separate", {"PU_NO_RELU_MASK_FUSE": "1"})):
+        f = str(tmp_path / f"{tag}.pt")
+        e = dict(os.environ); e.update(env)
+        r = subprocess.run([sys.executable, "-c", _MASK_SCRIPT, root, f], env=e, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(torch.load(f, weights_only=True))
+    assert outs[0].keys() == outs[1].keys() and len(outs[0]) > 8
+    for k in outs[0]:
+        assert torch.equal(outs[0][k], outs[1][k]), k
+    assert any(float(v.abs().max()) > 0 for v in outs[0].values())

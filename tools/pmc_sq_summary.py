@@ -14,10 +14,10 @@ dur = collections.defaultdict(float)
 for r in csv.DictReader(open(sys.argv[2])):
     dur[r['Kernel_Name']] += int(r['End_Timestamp']) - int(r['Start_Timestamp'])
 def tag(m):
-    mm = re.match(r"_ZN2pu\d+([a-z0-9_]+)I(DF16_|NS_4bf16E|f)((?:Li\d+E)*)", m)
+    mm = re.match(r"_ZN2pu\d+([a-z0-9_]+)I(DF16_|NS_4bf16E|f)((?:Li\d+E)*)((?:Lb[01]E)?)", m)
     if not mm: return m[:60]
     nums = re.findall(r"Li(\d+)E", mm.group(3))
-    return mm.group(1) + "<" + ",".join(["f16"] + nums) + ">"
+    return mm.group(1) + "<" + ",".join(["f16"] + nums + (["1"] if mm.group(4) == "Lb1E" else [])) + ">"
 rows = []
 for k, c in acc.items():
     if c.get('SQ_VALU_MFMA_BUSY_CYCLES', 0) <= 0: continue
