@@ -362,7 +362,10 @@ __device__ __forceinline__ void conv3_epilogue_lanes(int l, int wm, int W, unsig
     lpix[it] = (unsigned)((m / TW) * W + (m % TW));
   }
 }
-template <typename T, int NTM, int TW, int TH, int WM, bool GNB>
+// PRE: the residual / accumulate operands of all NIT vectors are loaded before the first use (conv3_kernel: the accumulators are staged, their
+// registers free - one memory latency instead of NIT dependent ones; conv3p keeps the per-vector form, its epilogue runs inside the tile loop
+// next to the resident weight fragments and 32 more registers would halve its occupancy)
+template <typename T, int NTM, int TW, int TH, int WM, bool GNB, bool PRE = false>
 __device__ __forceinline__ void conv3_epilogue_store(const ConvArgs& a, const T* stage, int l, int wm, int ct, int b, unsigned pixbase,
                                                      int tile_xy, int tiles_per_img, const unsigned* lpix) {
   constexpr int ERS = 40;
@@ -453,6 +456,18 @@ __device__ __forceinline__ void conv3_epilogue_store(const ConvArgs& a, const T*
   }
   const bool mod = res != nullptr || a.accumulate || a.relu || mk != nullptr;      // (wave-uniform)
   if (okc) {
+    typedef int ep_i32x4 __attribute__((ext_vector_type(4)));      // whole 128-bit values (a {w[4]} struct is split into scalars and re-joined
+    ep_i32x4 pre_r[PRE ? NIT : 1], pre_a[PRE ? NIT : 1];           // with copies behind an s_waitcnt right after the loads)
+    if constexpr (PRE) {
+      if (res) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) pre_r[it] = *reinterpret_cast<const ep_i32x4*>(res + (size_t)((pixbase + lpix[it]) * (unsigned)a.res_ld + co));
+      }
+      if (a.accumulate) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) pre_a[it] = *reinterpret_cast<const ep_i32x4*>(out + (size_t)((pixbase + lpix[it]) * (unsigned)a.out_ld + co));
+      }
+    }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int pw = (it * 64 + l) >> 2;                          // (pixel of the wave, 8-cout chunk ch)
@@ -464,12 +479,16 @@ __device__ __forceinline__ void conv3_epilogue_store(const ConvArgs& a, const T*
       V16 pk = raw;
       if (mod) {
         if (res) {
-          float r[8]; unpack<T>(*reinterpret_cast<const V16*>(res + (size_t)(pix * (unsigned)a.res_ld + co)), r);
+          float r[8];
+          if constexpr (PRE) unpack<T>(__builtin_bit_cast(V16, pre_r[it]), r);
+          else unpack<T>(*reinterpret_cast<const V16*>(res + (size_t)(pix * (unsigned)a.res_ld + co)), r);
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] += r[e];
         }
         if (a.accumulate) {
-          float r[8]; unpack<T>(*reinterpret_cast<const V16*>(op), r);
+          float r[8];
+          if constexpr (PRE) unpack<T>(__builtin_bit_cast(V16, pre_a[it]), r);
+          else unpack<T>(*reinterpret_cast<const V16*>(op), r);
 #pragma unroll
           for (int e = 0; e < 8; ++e) v[e] += r[e];
         }
@@ -548,10 +567,19 @@ __global__ __launch_bounds__(64 * WM * WN, (MS == 16 && TH * TW / WM <= 128) ? 2
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
   } else {
+    // the accumulators start from the bias (fetched here, under the latency of the first halo loads) instead of adding it in the epilogue
+    // behind eight dependent loads: D of v_mfma_f32_16x16x32 holds rows (couts) 4 (l >> 4) + r of column (pixel) l & 15
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < 2; ++h) {
+      f32x4 b4;
 #pragma unroll
-      for (int j = 0; j < NPG; ++j) acc4[h][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int r = 0; r < 4; ++r) {
+        const int co = ct * 32 + h * 16 + 4 * (l >> 4) + r;
+        b4[r] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < NPG; ++j) acc4[h][j] = b4;
+    }
   }
 
   int gi[NVI], li[NVI];
@@ -692,19 +720,11 @@ __global__ __launch_bounds__(64 * WM * WN, (MS == 16 && TH * TW / WM <= 128) ? 2
   T* stage = reinterpret_cast<T*>(smem_raw) + wave * (NTM * 32 * ERS);
   if constexpr (MS == 16) {
     // D of v_mfma_f32_16x16x32: lane holds rows (couts) 4 (l >> 4) + r, r = 0..3, of column (pixel) l & 15
-    float bq[2][4];
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int co = ct * 32 + h * 16 + 4 * (l >> 4) + r;
-        bq[h][r] = (a.bias && co < a.Cout) ? a.bias[co] : 0.f;
-      }
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
       for (int j = 0; j < NPG; ++j) {
-        float v[4] = {acc4[h][j][0] + bq[h][0], acc4[h][j][1] + bq[h][1], acc4[h][j][2] + bq[h][2], acc4[h][j][3] + bq[h][3]};
+        float v[4] = {acc4[h][j][0], acc4[h][j][1], acc4[h][j][2], acc4[h][j][3]};
         store4<T>(stage + (j * 16 + (l & 15)) * ERS + h * 16 + 4 * (l >> 4), v);
       }
   } else {
@@ -725,8 +745,8 @@ __global__ __launch_bounds__(64 * WM * WN, (MS == 16 && TH * TW / WM <= 128) ? 2
   }
   unsigned lpix[NTM * 2];
   conv3_epilogue_lanes<NTM, TW>(l, wm, a.W, lpix);
-  conv3_epilogue_store<T, NTM, TW, TH, WM, GNB>(a, stage, l, wm, ct, b, (unsigned)((b * a.H + ty0) * a.W + tx0), (ty0 / TH) * tiles_x + tx0 / TW,
-                                                tiles_x * tiles_y, lpix);
+  conv3_epilogue_store<T, NTM, TW, TH, WM, GNB, true>(a, stage, l, wm, ct, b, (unsigned)((b * a.H + ty0) * a.W + tx0), (ty0 / TH) * tiles_x + tx0 / TW,
+                                                      tiles_x * tiles_y, lpix);
 }
 
 // ------------------------------------------------------------------ conv3p: persistent variant for K <= 64 input channels
