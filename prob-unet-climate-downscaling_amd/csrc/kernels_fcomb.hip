@@ -404,9 +404,14 @@ __global__ __launch_bounds__(256, NCO > 0 ? 2 : 1) void fcomb_bwd16_kernel(Fcomb
       M::set(w1tp[s], e, f.w1[fc_perm(s, h, e) * 32 + j]);
       M::set(w0tp[s], e, f.w0[fc_perm(s, h, e) * WS + j]);
     }
-  float b1r[16];
+  // compact form: the layer-1 bias and the W2 rows live in LDS (read as broadcasts where they are used) - in registers they were the 32 that
+  // pushed the kernel over its 256 (27 spilled dwords whose reloads share vmcnt with the dout / feature prefetches: every member iteration
+  // began with s_waitcnt vmcnt(0), i.e. paid the HBM latency of the load issued just before)
+  float b1r[NCO > 0 ? 1 : 16];
+  if constexpr (NCO == 0) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) b1r[r] = f.b1[fc_row(r, h)];
+    for (int r = 0; r < 16; ++r) b1r[r] = f.b1[fc_row(r, h)];
+  }
   typename M::Frag ones;
 #pragma unroll
   for (int e = 0; e < 8; ++e) M::set(ones, e, 1.f);
@@ -416,26 +421,33 @@ __global__ __launch_bounds__(256, NCO > 0 ? 2 : 1) void fcomb_bwd16_kernel(Fcomb
   for (int r = 0; r < 16; ++r) { aw[0][r] = 0.f; aw[1][r] = 0.f; aw[2][r] = 0.f; as1[r] = 0.f; as2[r] = 0.f; }
   // compact last layer: W2 rows of this lane's channels, per-lane partial sums of dW2 / db2 over the lane's own pixels
   constexpr int NC = NCO > 0 ? NCO : 1;
-  float w2r[NC][16], aw2v[NC][16], ab2v[NC];
+  float aw2v[NC][16], ab2v[NC];
 #pragma unroll
   for (int co = 0; co < NC; ++co) {
     ab2v[co] = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { w2r[co][r] = (NCO > 0) ? f.w2[co * 32 + fc_row(r, h)] : 0.f; aw2v[co][r] = 0.f; }
+    for (int r = 0; r < 16; ++r) aw2v[co][r] = 0.f;
   }
   // transposed-read lane roles
   const int g = l >> 4, q = (l & 15) >> 2, p = l & 3;
   const int nchunks = (int)((HW + CHP - 1) / CHP);
   float* dzs = zbs + f.M * 32;                                      // [M][32]: this block's share of d(loss)/d(zb), flushed once at the end
   for (int i = tid; i < f.M * 32; i += 256) { zbs[i] = zb[((long)(i >> 5) * f.B + b) * 32 + (i & 31)]; dzs[i] = 0.f; }
+  float* b1s = dzs + f.M * 32;                                     // [32] layer-1 bias, [NCO][32] W2 rows (compact form)
+  float* w2s = b1s + 32;
+  if constexpr (NCO > 0) {
+    if (tid < 32) b1s[tid] = f.b1[tid];
+    for (int i = tid; i < NCO * 32; i += 256) w2s[i] = f.w2[i];
+  }
   __syncthreads();
   // dout of the next member is fetched while the current one is processed (HBM latency off the dependent chain).  Compact
   // form for Cout <= 4 (rows 0..3 live in the h == 0 half of both layouts); wider outputs load in place.
   const bool small_co = f.Cout <= 4;
   auto load_dout4 = [&](int m, long pix, bool valid, float* dn) {
-    if constexpr (NCO > 0) {                                 // both lane halves of a pixel need its dout values
-#pragma unroll
-      for (int e = 0; e < 4; ++e) dn[e] = (valid && e < NCO) ? a.dout[(((long)b * f.M + m) * NCO + e) * HW + pix] : 0.f;
+    if constexpr (NCO > 0) {                                 // both lane halves of a pixel need its dout values.  Unconditional loads from a
+      const long pc = pix < HW ? pix : HW - 1;               // clamped pixel (zeroed where they are USED): a select next to the load makes the
+#pragma unroll                                               // wave wait for it at once, and an exec-masked load is a branch per load
+      for (int e = 0; e < 4; ++e) dn[e] = e < NCO ? a.dout[(((long)b * f.M + m) * NCO + e) * HW + pc] : 0.f;
     } else {
 #pragma unroll
       for (int e = 0; e < 4; ++e) dn[e] = (valid && small_co && h == 0 && e < f.Cout) ? a.dout[(((long)b * f.M + m) * f.Cout + e) * HW + pix] : 0.f;
@@ -444,6 +456,13 @@ __global__ __launch_bounds__(256, NCO > 0 ? 2 : 1) void fcomb_bwd16_kernel(Fcomb
   // the feature rows of the NEXT chunk are fetched while the members of the current one are processed
   V16 nxf[2];
   auto load_feat = [&](int ch, V16* out) {
+    if constexpr (NCO > 0) {                                  // unconditional, clamped (rows beyond the image are masked by `valid` below;
+      long pix = (long)(ch < nchunks ? ch : nchunks - 1) * CHP + wave * 32 + j;      // a chunk beyond the last is never used)
+      if (pix >= HW) pix = HW - 1;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) out[s] = *reinterpret_cast<const V16*>(fp + pix * f.feat.ld + 16 * s + 8 * h);
+      return;
+    }
     const long pix = (long)ch * CHP + wave * 32 + j;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
@@ -452,6 +471,8 @@ __global__ __launch_bounds__(256, NCO > 0 ? 2 : 1) void fcomb_bwd16_kernel(Fcomb
     }
   };
   load_feat(blockIdx.x, nxf);
+  float dn[4];                                               // dout of the next (chunk, member): fetched one member ahead, across chunk boundaries too
+  load_dout4(0, (long)blockIdx.x * CHP + wave * 32 + j, (long)blockIdx.x * CHP + wave * 32 + j < HW, dn);
   for (int ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
     // ---- per-wave: two 32-pixel column tiles; feat fragments and the shared pre-activation
     f32x16 pre, dfe;
@@ -476,19 +497,18 @@ __global__ __launch_bounds__(256, NCO > 0 ? 2 : 1) void fcomb_bwd16_kernel(Fcomb
       pre = M::mfma(w.w0n[1], fb[1], pre);
     }
     load_feat(ch + gridDim.x, nxf);
-    float dn[4];
-    load_dout4(0, pix, valid, dn);
     for (int m = 0; m < f.M; ++m) {
       const float* zbm = zbs + m * 32;
-      const float dc[4] = {dn[0], dn[1], dn[2], dn[3]};
+      const float dc[4] = {(NCO == 0 || valid) ? dn[0] : 0.f, (NCO == 0 || valid) ? dn[1] : 0.f, (NCO == 0 || valid) ? dn[2] : 0.f, (NCO == 0 || valid) ? dn[3] : 0.f};
       if (m + 1 < f.M) load_dout4(m + 1, pix, valid, dn);
+      else { const long pn = pix + (long)gridDim.x * CHP; load_dout4(0, pn, pn < HW, dn); }      // first member of this wave's next chunk (clamped)
       __builtin_amdgcn_wave_barrier();
       {
         f32x16 h0, h1, acc, d1, d0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) h0[r] = fmaxf(pre[r] + zbm[fc_row(r, h)], 0.f);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = b1r[r];
+        for (int r = 0; r < 16; ++r) acc[r] = NCO > 0 ? b1s[fc_row(r, h)] : b1r[NCO > 0 ? 0 : r];
         acc = M::mfma(w.w1p[0], fc_acc_frag<T>(h0, 0), acc);
         acc = M::mfma(w.w1p[1], fc_acc_frag<T>(h0, 1), acc);
 #pragma unroll
@@ -502,7 +522,7 @@ __global__ __launch_bounds__(256, NCO > 0 ? 2 : 1) void fcomb_bwd16_kernel(Fcomb
           for (int r = 0; r < 16; ++r) {
             float t = 0.f;
 #pragma unroll
-            for (int co = 0; co < NCO; ++co) { t += w2r[co][r] * dc[co]; aw2v[co][r] += dc[co] * h1[r]; }
+            for (int co = 0; co < NCO; ++co) { t += w2s[co * 32 + fc_row(r, h)] * dc[co]; aw2v[co][r] += dc[co] * h1[r]; }
             acc[r] = t;
           }
           if (h == 0) {
@@ -738,7 +758,7 @@ hipError_t launch_fcomb_bwd(const FcombBwdArgs& a, hipStream_t s) {
       long per_sample = 24;                              // general kernel: three rounds of 256 blocks at B = 32 (round-2 tuning)
       if (per_cu == 2) { per_sample = 512 / (f.B > 0 ? f.B : 1); if (per_sample < 1) per_sample = 1; }
       dim3 grid16((unsigned)min(per_sample, (HW + 127) / 128), f.B);
-      hipLaunchKernelGGL(kern, grid16, dim3(256), 6 * 128 * 32 * 2 + (size_t)2 * f.M * 32 * 4, s, a, zb, dzb);
+      hipLaunchKernelGGL(kern, grid16, dim3(256), 6 * 128 * 32 * 2 + (size_t)2 * f.M * 32 * 4 + 5 * 32 * 4, s, a, zb, dzb);
     }
   } else if (f.F == 32) hipLaunchKernelGGL((fcomb_bwd_kernel<T, 32>), grid, dim3(256), lds, s, a, zb, dzb);
   else if (f.F == 16) hipLaunchKernelGGL((fcomb_bwd_kernel<T, 16>), grid, dim3(256), lds, s, a, zb, dzb);
