@@ -82,7 +82,7 @@ template <> struct MM<float> {
 
 template <typename T> __device__ __forceinline__ void lds_store_vec(T* dst, const V16& v) { *reinterpret_cast<V16*>(dst) = v; }
 template <> __device__ __forceinline__ void lds_store_vec<float>(float* dst, const V16& v) {   // rows are 33 dwords: not 16B aligned
-  dst[0] = __uint_as_float(v.w[0]); dst[1] = __uint_as_float(v.w[1]); dst[2] = __uint_as_float(v.w[2]); dst[3] = __uint_as_float(v.w[3]);
+  dst[0] = __uint_as_float(v[0]); dst[1] = __uint_as_float(v[1]); dst[2] = __uint_as_float(v[2]); dst[3] = __uint_as_float(v[3]);
 }
 
 template <typename T> __device__ __forceinline__ void load4(const T* p, float* o);
@@ -606,7 +606,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MS == 16 && TH * TW / WM <= 128) ? 2
     for (int k = 0; k < NVI; ++k) {
       const bool ok = gi[k] >= 0 && c0 + (li[k] % KCP) < a.Cin;
       const V16 v = *reinterpret_cast<const V16*>(in + (ok ? (ptrdiff_t)((size_t)(unsigned)gi[k] + c0) : zoff));
-      ri[k].w[0] = v.w[0]; ri[k].w[1] = v.w[1]; ri[k].w[2] = v.w[2]; ri[k].w[3] = v.w[3];
+      ri[k] = v;
     }
   };
   auto lstore = [&](int buf, int) {
@@ -845,7 +845,7 @@ __global__ __launch_bounds__(64 * WM * WN, ((GNB || PF == 2) && NCH == 1 && WN =
       for (int c = 0; c < NCH; ++c) {
         // (element offset of the zero page relative to `in`: one offset select per vector, no post-processing: the load stays in flight)
         const V16 v = *reinterpret_cast<const V16*>(in + ((inimg && chan_ok[c]) ? (ptrdiff_t)(off + (unsigned)(c * KC)) : zoff));
-        ri[c][k].w[0] = v.w[0]; ri[c][k].w[1] = v.w[1]; ri[c][k].w[2] = v.w[2]; ri[c][k].w[3] = v.w[3];
+        ri[c][k] = v;
       }
     }
   };

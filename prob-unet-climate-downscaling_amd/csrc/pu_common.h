@@ -48,11 +48,13 @@ template <> struct ET<bf16> {
 };
 
 // 16-byte vector of T as raw bits
-struct alignas(16) V16 { uint32_t w[4]; };
+// a NATIVE 128-bit vector (round 3; was `struct alignas(16) V16 { uint32_t w[4]; }`): arrays of the struct were split into scalars by SROA and re-joined
+// with v_mov copies behind an s_waitcnt vmcnt right after the loads that filled them - loads meant to be in flight together were serialised
+typedef uint32_t V16 __attribute__((ext_vector_type(4)));
 
 template <typename T> __device__ __forceinline__ void unpack(const V16& v, float* out);   // VEC floats
 template <> __device__ __forceinline__ void unpack<float>(const V16& v, float* o) {
-  o[0] = __uint_as_float(v.w[0]); o[1] = __uint_as_float(v.w[1]); o[2] = __uint_as_float(v.w[2]); o[3] = __uint_as_float(v.w[3]);
+  o[0] = __uint_as_float(v[0]); o[1] = __uint_as_float(v[1]); o[2] = __uint_as_float(v[2]); o[3] = __uint_as_float(v[3]);
 }
 template <> __device__ __forceinline__ void unpack<f16>(const V16& v, float* o) {
   const f16* h = reinterpret_cast<const f16*>(&v);
@@ -61,11 +63,11 @@ template <> __device__ __forceinline__ void unpack<f16>(const V16& v, float* o) 
 }
 template <> __device__ __forceinline__ void unpack<bf16>(const V16& v, float* o) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) { o[2 * i] = __uint_as_float(v.w[i] << 16); o[2 * i + 1] = __uint_as_float(v.w[i] & 0xffff0000u); }
+  for (int i = 0; i < 4; ++i) { o[2 * i] = __uint_as_float(v[i] << 16); o[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u); }
 }
 template <typename T> __device__ __forceinline__ V16 pack(const float* in);
 template <> __device__ __forceinline__ V16 pack<float>(const float* in) {
-  V16 v; v.w[0] = __float_as_uint(in[0]); v.w[1] = __float_as_uint(in[1]); v.w[2] = __float_as_uint(in[2]); v.w[3] = __float_as_uint(in[3]); return v;
+  V16 v; v[0] = __float_as_uint(in[0]); v[1] = __float_as_uint(in[1]); v[2] = __float_as_uint(in[2]); v[3] = __float_as_uint(in[3]); return v;
 }
 template <> __device__ __forceinline__ V16 pack<f16>(const float* in) {
   V16 v; f16* h = reinterpret_cast<f16*>(&v);
@@ -76,10 +78,10 @@ template <> __device__ __forceinline__ V16 pack<f16>(const float* in) {
 template <> __device__ __forceinline__ V16 pack<bf16>(const float* in) {
   V16 v;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) v.w[i] = f2_to_bf16x2(in[2 * i], in[2 * i + 1]);
+  for (int i = 0; i < 4; ++i) v[i] = f2_to_bf16x2(in[2 * i], in[2 * i + 1]);
   return v;
 }
-__device__ __forceinline__ V16 zero16() { V16 v; v.w[0] = v.w[1] = v.w[2] = v.w[3] = 0; return v; }
+__device__ __forceinline__ V16 zero16() { V16 v; v[0] = v[1] = v[2] = v[3] = 0; return v; }
 
 // ------------------------------------------------------------------ tensor view (NHWC, strided pixel rows)
 struct TV {
