@@ -396,10 +396,23 @@ __global__ __launch_bounds__(256) void wgrad_reduce2_kernel(const float* __restr
     for (int i = 0; i < 8; ++i) sb[i] = 0.f;
     int k = bl;
     for (; k + 7 * 16 < split; k += 8 * 16) {
+      float v[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) sb[i] += bs[(size_t)(k + i * 16) * cout_pad];
+      for (int i = 0; i < 8; ++i) v[i] = bs[(size_t)(k + i * 16) * cout_pad];
+      __builtin_amdgcn_sched_barrier(0);            // loads first: left alone, the scheduler re-uses ONE register quad and issues load, wait, add eight times
+#pragma unroll
+      for (int i = 0; i < 8; ++i) sb[i] += v[i];
     }
-    for (; k < split; k += 16) sb[0] += bs[(size_t)k * cout_pad];
+    // the tail in ONE batch of loads from clamped rows (selected where they are added): `sb[0] += bs[...]` per remaining row was a chain of
+    // dependent memory round trips - at the usual split of 64 (four rows per lane) the whole reduction, 10 us, was four latencies long
+    if (k < split) {
+      float v[7];
+#pragma unroll
+      for (int i = 0; i < 7; ++i) { const int kk = k + i * 16; v[i] = bs[(size_t)(kk < split ? kk : k) * cout_pad]; }
+      __builtin_amdgcn_sched_barrier(0);            // loads first: left alone, the scheduler re-uses ONE register quad and issues load, wait, add eight times
+#pragma unroll
+      for (int i = 0; i < 7; ++i) sb[i] += (k + i * 16 < split) ? v[i] : 0.f;
+    }
     bred[threadIdx.x] = ((sb[0] + sb[1]) + (sb[2] + sb[3])) + ((sb[4] + sb[5]) + (sb[6] + sb[7]));
     __syncthreads();
     if (bl == 0 && co < Cout) {
@@ -429,11 +442,27 @@ __global__ __launch_bounds__(256) void wgrad_reduce2_kernel(const float* __restr
     if (live) {
       const float* p = slab + e;
       if (ALLT && NT > 1) {
-        for (int k = lane; k < split; k += L) {              // NT independent 16-byte loads in flight per trip
+        int k = lane;
+        for (; k + L < split; k += 2 * L) {                  // two slabs = 2 NT independent 16-byte loads in flight per trip
+          const float* pk = p + (size_t)k * stride;
+          const float* pk2 = pk + (size_t)L * stride;
+          f32x4 v[NT], w[NT];
+#pragma unroll
+          for (int t = 0; t < NT; ++t) v[t] = *reinterpret_cast<const f32x4*>(pk + (size_t)t * per_tap);
+#pragma unroll
+          for (int t = 0; t < NT; ++t) w[t] = *reinterpret_cast<const f32x4*>(pk2 + (size_t)t * per_tap);
+          __builtin_amdgcn_sched_barrier(0);            // loads first: left alone, the scheduler re-uses ONE register quad and issues load, wait, add eight times
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[t] += v[t];
+#pragma unroll
+          for (int t = 0; t < NT; ++t) acc[t] += w[t];
+        }
+        if (k < split) {
           const float* pk = p + (size_t)k * stride;
           f32x4 v[NT];
 #pragma unroll
           for (int t = 0; t < NT; ++t) v[t] = *reinterpret_cast<const f32x4*>(pk + (size_t)t * per_tap);
+          __builtin_amdgcn_sched_barrier(0);            // loads first: left alone, the scheduler re-uses ONE register quad and issues load, wait, add eight times
 #pragma unroll
           for (int t = 0; t < NT; ++t) acc[t] += v[t];
         }
@@ -446,10 +475,18 @@ __global__ __launch_bounds__(256) void wgrad_reduce2_kernel(const float* __restr
           f32x4 v[8];
 #pragma unroll
           for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const f32x4*>(p + (size_t)(k + i * L) * stride);
+          __builtin_amdgcn_sched_barrier(0);            // loads first: left alone, the scheduler re-uses ONE register quad and issues load, wait, add eight times
 #pragma unroll
           for (int i = 0; i < 8; ++i) sa[i] += v[i];
         }
-        for (; k < split; k += L) sa[0] += *reinterpret_cast<const f32x4*>(p + (size_t)k * stride);
+        if (k < split) {                                     // tail: one batch from clamped slabs (see the bias rows above)
+          f32x4 v[7];
+#pragma unroll
+          for (int i = 0; i < 7; ++i) { const int kk = k + i * L; v[i] = *reinterpret_cast<const f32x4*>(p + (size_t)(kk < split ? kk : k) * stride); }
+          __builtin_amdgcn_sched_barrier(0);            // loads first: left alone, the scheduler re-uses ONE register quad and issues load, wait, add eight times
+#pragma unroll
+          for (int i = 0; i < 7; ++i) { if (k + i * L < split) sa[i] += v[i]; }
+        }
         acc[0] = ((sa[0] + sa[1]) + (sa[2] + sa[3])) + ((sa[4] + sa[5]) + (sa[6] + sa[7]));
       }
     }
