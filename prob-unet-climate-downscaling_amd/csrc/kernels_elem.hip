@@ -166,6 +166,11 @@ __global__ __launch_bounds__(NT) void gn_finalize_kernel(TV x, const float* __re
   __shared__ float gs[64];
   const int b = blockIdx.x, tid = threadIdx.x, C = x.C;
   const long HW = (long)x.H * x.W;
+  // this thread's affine parameters, fetched under the reductions below (they used to be four more dependent memory round trips at the end of
+  // a kernel that is nothing but a chain of them)
+  const bool own = tid < C;
+  const float pg = own ? gamma[tid] : 0.f, pb = own ? beta[tid] : 0.f;
+  const float psc = (own && scale) ? scale[tid] : 0.f, psh = (own && shift) ? shift[tid] : 0.f;
   if (ps0) {
     // producer-fused statistics: unshifted (sum, sum of squares) rows, one per producing wave; `nl` threads share a channel
     for (int src = 0; src < 2; ++src) {
@@ -226,8 +231,10 @@ __global__ __launch_bounds__(NT) void gn_finalize_kernel(TV x, const float* __re
   for (int c = tid; c < C; c += NT) {
     const int g = c / cpg;
     const float rstd = gs[g * 2 + 1];
-    const float sc = scale ? scale[c] : 0.f, t = shift ? shift[c] : 0.f;
-    float4 o4; o4.x = rstd * gamma[c] * (1.f + sc); o4.y = beta[c] * (1.f + sc) + t; o4.z = gs[g * 2]; o4.w = rstd;
+    const bool first = c == tid;                    // (C <= NT in every plan: one channel per thread)
+    const float sc = first ? psc : (scale ? scale[c] : 0.f), t = first ? psh : (shift ? shift[c] : 0.f);
+    const float gm = first ? pg : gamma[c], bt = first ? pb : beta[c];
+    float4 o4; o4.x = rstd * gm * (1.f + sc); o4.y = bt * (1.f + sc) + t; o4.z = gs[g * 2]; o4.w = rstd;
     reinterpret_cast<float4*>(coef)[(long)b * C + c] = o4;      // per channel: (A, Bp, group mean, group rstd)
   }
 }
@@ -548,6 +555,13 @@ __global__ __launch_bounds__(NT) void gn_bwd_finalize_kernel(GNBwdArgs a) {
   const GNArgs& f = a.f;
   const int b = blockIdx.x, tid = threadIdx.x, C = f.x.C, G = f.G, cpg = C / G;
   const long HW = (long)f.x.H * f.x.W;
+  // everything that does not depend on the row sums is fetched first, under them (this kernel is a chain of dependent memory round
+  // trips: rows -> group means -> coefficients; the parameter and statistics loads used to be three more links at its end)
+  __shared__ float gpl[1024];
+  const bool own = tid < C;
+  const float p_gamma = own ? f.gamma[tid] : 0.f, p_beta = own ? f.beta[tid] : 0.f, p_sc = (own && f.scale) ? f.scale[tid] : 0.f;
+  const float p_rstd = own ? f.stat[((long)b * G + tid / cpg) * 2 + 1] : 0.f;
+  if (own) gpl[tid] = p_gamma * (1.f + p_sc);
   {
     // per-channel totals of the pass-1 rows: nl threads share a channel (with C = 32 a one-thread-per-channel loop would
     // leave 224 of the block's 256 threads idle behind 64 dependent loads)
@@ -560,7 +574,14 @@ __global__ __launch_bounds__(NT) void gn_bwd_finalize_kernel(GNBwdArgs a) {
       float u = 0.f, w = 0.f;
       if (c < C && lane < nl) {
         const float2* pp = part + ((long)b * nk + lane) * C + c;
-        for (int k = lane; k < nk; k += nl, pp += (long)nl * C) { const float2 v = *pp; u += v.x; w += v.y; }
+        const long st = (long)nl * C;
+        int k = lane;
+        for (; k + 3 * nl < nk; k += 4 * nl, pp += 4 * st) {           // four independent loads in flight per trip (the dv epilogue's rows:
+          const float2 v0 = pp[0], v1 = pp[st], v2 = pp[2 * st], v3 = pp[3 * st];      // 256 per sample at the 256 x 256 level)
+          __builtin_amdgcn_sched_barrier(0);
+          u += (v0.x + v1.x) + (v2.x + v3.x); w += (v0.y + v1.y) + (v2.y + v3.y);
+        }
+        for (; k < nk; k += nl, pp += st) { const float2 v = *pp; u += v.x; w += v.y; }
       }
       red[tid * 2] = u; red[tid * 2 + 1] = w;
       __syncthreads();
@@ -574,7 +595,7 @@ __global__ __launch_bounds__(NT) void gn_bwd_finalize_kernel(GNBwdArgs a) {
   if (tid < G) {
     float m1 = 0.f, m2 = 0.f;
     for (int c = tid * cpg; c < (tid + 1) * cpg; ++c) {
-      const float gp = f.gamma[c] * (1.f + (f.scale ? f.scale[c] : 0.f));
+      const float gp = c < NT ? gpl[c] : f.gamma[c] * (1.f + (f.scale ? f.scale[c] : 0.f));
       m1 += gp * cs[c * 2]; m2 += gp * cs[c * 2 + 1];
     }
     const float n = (float)cpg * (float)HW;
@@ -583,20 +604,21 @@ __global__ __launch_bounds__(NT) void gn_bwd_finalize_kernel(GNBwdArgs a) {
   __syncthreads();
   for (int c = tid; c < C; c += NT) {
     const int g = c / cpg;
-    const float mean = f.stat[((long)b * G + g) * 2], rstd = f.stat[((long)b * G + g) * 2 + 1];
-    const float gp = f.gamma[c] * (1.f + (f.scale ? f.scale[c] : 0.f));
+    const bool first = c == tid;                     // (C <= NT in every plan: one channel per thread)
+    const float rstd = first ? p_rstd : f.stat[((long)b * G + g) * 2 + 1];
+    const float gam = first ? p_gamma : f.gamma[c], bet = first ? p_beta : f.beta[c];
+    const float sc = first ? p_sc : (f.scale ? f.scale[c] : 0.f);
+    const float gp = gam * (1.f + sc);
     const float m1 = gm[g * 2], m2 = gm[g * 2 + 1];
     float* o = a.coef2 + ((long)b * C + c) * 3;
     o[0] = rstd * gp;                  // dx = o0 dv + o1 (x - mean) + o2
     o[1] = -rstd * rstd * m2;
     o[2] = -rstd * m1;
-    (void)mean;
     // parameter gradients: this sample's contribution (fp32 atomics over the B samples; ADDED into the flat gradient)
     const float S1 = cs[c * 2] * a.inv_scale, S2 = cs[c * 2 + 1] * a.inv_scale;
-    const float sc = f.scale ? f.scale[c] : 0.f;
     atomicAdd(a.dgamma + c, (1.f + sc) * S2);
     atomicAdd(a.dbeta + c, (1.f + sc) * S1);
-    if (a.dscale) atomicAdd(a.dscale + c, f.gamma[c] * S2 + f.beta[c] * S1);
+    if (a.dscale) atomicAdd(a.dscale + c, gam * S2 + bet * S1);
     if (a.dshift) atomicAdd(a.dshift + c, S1);
   }
 }
