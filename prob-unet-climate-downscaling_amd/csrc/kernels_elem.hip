@@ -452,7 +452,7 @@ __device__ __forceinline__ void gn_dv_math(const GNArgs& f, const DyRaw<T, RS>& 
   for (int e = 0; e < VEC; ++e) dv[e] = dh[e] * dsilu_f<sizeof(T) == 4>(A[e] * (xv[e] - mu[e]) + Bc[e]);
 }
 
-template <typename T, int RS>
+template <typename T, int RS, int UN = 4>      // UN: see gn_bwd_pass2_kernel
 __global__ __launch_bounds__(256) void gn_bwd_pass1_kernel(GNBwdArgs a) {
   constexpr int VEC = ET<T>::VEC;
   __shared__ float buf[256 * VEC * 2];
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(256) void gn_bwd_pass1_kernel(GNBwdArgs a) {
     if (RS == RS_NONE) {
       // four pixels per trip with all eight 16-byte loads issued before the first use: a thread walks ~16 pixels, and one
       // load -> exp -> accumulate round per pixel left this pass latency-bound (2.8 TB/s) rather than HBM-bound
-      constexpr int U = 4;
+      constexpr int U = UN;
       const T* dyp = reinterpret_cast<const T*>(a.dy.p);
       const uint32_t dkey = drop_key(f.drop_seed, f.drop_stream), dthr = drop_thr16(keep);
       for (long p = p0 + pl; p < p1; p += (long)PL * U) {
@@ -624,7 +624,9 @@ __global__ __launch_bounds__(NT) void gn_bwd_finalize_kernel(GNBwdArgs a) {
 }
 
 // DV: `dy` already holds dv (written by the data-gradient epilogue, GNBwdFuse): no mask, no silu' - two reads, two FMAs per element
-template <typename T, int RS, bool DV = false>
+// UN = pixels per trip in the un-resampled path: 4, or 2 for tensors up to ~134 MB (148 instead of 194-210 registers: three waves per SIMD
+// instead of two; -8...12 % there, +4...9 % on the larger concat-width tensors - tools/gn_microbench.py, profiles/r3_experiments.txt [F])
+template <typename T, int RS, bool DV = false, int UN = 4>
 __global__ __launch_bounds__(256) void gn_bwd_pass2_kernel(GNBwdArgs a) {
   constexpr int VEC = ET<T>::VEC;
   const GNArgs& f = a.f;
@@ -643,8 +645,8 @@ __global__ __launch_bounds__(256) void gn_bwd_pass2_kernel(GNBwdArgs a) {
 #pragma unroll
   for (int e = 0; e < VEC; ++e) { const float4 q4 = q1[e]; A[e] = q4.x; Bc[e] = q4.y; mu[e] = q4.z; c0[e] = q2[3 * e]; c1[e] = q2[3 * e + 1]; c2[e] = q2[3 * e + 2]; }
   if (RS == RS_NONE) {
-    // four pixels per trip, every load issued before the first use (see gn_bwd_pass1_kernel)
-    constexpr int U = 4;
+    // UN pixels per trip, every load issued before the first use (see gn_bwd_pass1_kernel)
+    constexpr int U = UN;
     const T* dyp = reinterpret_cast<const T*>(a.dy.p);
     const uint32_t dkey = drop_key(f.drop_seed, f.drop_stream), dthr = drop_thr16(keep);
     for (long p = p0 + pl; p < p1; p += (long)PL * U) {
@@ -898,7 +900,8 @@ hipError_t launch_gn_bwd_parts(const GNBwdArgs& a, int parts, hipStream_t s) {
   if ((parts & 1) && !dvrows) {
     dim3 g1(f.nchunk, f.x.B);
     if (prof) gn_prof_begin("gn_bwd_pass1", f.resample, f.x, xb + dyb, s, a.dy.ld, a.dx.ld, (f.drop_p > 0.f) + 2 * a.accumulate + 4 * (a.add.p != nullptr));
-    if (f.resample == RS_NONE) hipLaunchKernelGGL((gn_bwd_pass1_kernel<T, RS_NONE>), g1, dim3(256), 0, s, a);
+    if (f.resample == RS_NONE && (double)f.x.B * f.x.H * f.x.W * f.x.C * sizeof(T) <= 140e6) hipLaunchKernelGGL((gn_bwd_pass1_kernel<T, RS_NONE, 2>), g1, dim3(256), 0, s, a);
+    else if (f.resample == RS_NONE) hipLaunchKernelGGL((gn_bwd_pass1_kernel<T, RS_NONE>), g1, dim3(256), 0, s, a);
     else if (f.resample == RS_DOWN) hipLaunchKernelGGL((gn_bwd_pass1_kernel<T, RS_DOWN>), g1, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((gn_bwd_pass1_kernel<T, RS_UP>), g1, dim3(256), 0, s, a);
     if (prof) prof_record("", 0, 0, s, false);
@@ -907,7 +910,10 @@ hipError_t launch_gn_bwd_parts(const GNBwdArgs& a, int parts, hipStream_t s) {
   if (parts & 2) {
     const dim3 g2(gn_pix_blocks((long)f.x.H * f.x.W, f.x.C / ET<T>::VEC, f.x.B), f.x.B);
     if (prof) gn_prof_begin(dvrows ? "gn_bwd_pass2_dv" : "gn_bwd_pass2", f.resample, f.x, p2b, s, a.dy.ld, a.dx.ld, (f.drop_p > 0.f) + 2 * a.accumulate + 4 * (a.add.p != nullptr));
-    if (dvrows) hipLaunchKernelGGL((gn_bwd_pass2_kernel<T, RS_NONE, true>), g2, dim3(256), 0, s, a);
+    const bool narrow = (double)f.x.B * f.x.H * f.x.W * f.x.C * sizeof(T) <= 140e6;      // see gn_bwd_pass2_kernel: UN
+    if (dvrows && narrow) hipLaunchKernelGGL((gn_bwd_pass2_kernel<T, RS_NONE, true, 2>), g2, dim3(256), 0, s, a);
+    else if (dvrows) hipLaunchKernelGGL((gn_bwd_pass2_kernel<T, RS_NONE, true>), g2, dim3(256), 0, s, a);
+    else if (f.resample == RS_NONE && narrow) hipLaunchKernelGGL((gn_bwd_pass2_kernel<T, RS_NONE, false, 2>), g2, dim3(256), 0, s, a);
     else if (f.resample == RS_NONE) hipLaunchKernelGGL((gn_bwd_pass2_kernel<T, RS_NONE>), g2, dim3(256), 0, s, a);
     else if (f.resample == RS_DOWN) hipLaunchKernelGGL((gn_bwd_pass2_kernel<T, RS_DOWN>), g2, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((gn_bwd_pass2_kernel<T, RS_UP>), g2, dim3(256), 0, s, a);
