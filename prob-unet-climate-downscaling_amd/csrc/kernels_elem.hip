@@ -369,6 +369,107 @@ static inline void gn_prof_begin(const char* what, int rs, const TV& x, double b
   prof_record(tag, 0, bytes, s, true);
 }
 
+// Small tensors (H * W <= 1024: the 32 x 32 and 16 x 16 levels), statistics from the producing convolution's epilogue, no resampling: ONE kernel
+// instead of finalize + apply.  A block = (sample, bundle of whole groups, as gn_small_bwd_kernel): it reduces the producer rows of its own channels
+// (fp64, fixed order), forms the group statistics and the per-channel coefficients (written out: the backward reads them), and applies them to the
+// bundle's channels over all pixels.  At these sizes the two-kernel form is two 7-12 us launch-bound kernels with a 1.7 us gap between them.
+static inline int gn_bundle_channels(int C, int G);
+template <typename T>
+__global__ __launch_bounds__(256) void gn_small_fwd_kernel(GNArgs a, int CB) {
+  constexpr int VEC = 8;
+  static_assert(ET<T>::VEC == 8, "16-bit engines");
+  __shared__ double red[256 * 2];
+  __shared__ double cs[64 * 2];                            // per channel of the bundle: mean_c, M2_c
+  __shared__ float gs[64 * 2];                             // per group of the bundle: mean, rstd
+  __shared__ float cof[64 * 3];                            // per channel: A, Bp, group mean
+  const int C = a.x.C, G = a.G, cpg = C / G, b = blockIdx.y, c0 = blockIdx.x * CB, tid = threadIdx.x;
+  const long HW = (long)a.x.H * a.x.W;
+  const int pc0 = a.pc0 < C ? a.pc0 : C;
+  {
+    const int nl = 256 / CB, cl = tid % CB, lane = tid / CB, c = c0 + cl;
+    const bool s1 = c >= pc0;
+    const float* ps = s1 ? a.ps1 : a.ps0;
+    const int Cs = s1 ? C - pc0 : pc0, cc = s1 ? c - pc0 : c, ns = s1 ? a.ns1 : a.ns0;
+    double sa = 0, sq = 0;
+    if (lane < nl) {
+      const float2* pp = reinterpret_cast<const float2*>(ps) + ((long)b * ns + lane) * Cs + cc;
+      const long st = (long)nl * Cs;
+      int k = lane;
+      for (; k + 3 * nl < ns; k += 4 * nl, pp += 4 * st) {                // four independent loads in flight per trip
+        const float2 v0 = pp[0], v1 = pp[st], v2 = pp[2 * st], v3 = pp[3 * st];
+        __builtin_amdgcn_sched_barrier(0);
+        sa += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
+        sq += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
+      }
+      for (; k < ns; k += nl, pp += st) { const float2 v = *pp; sa += v.x; sq += v.y; }
+    }
+    red[tid * 2] = sa; red[tid * 2 + 1] = sq;
+    __syncthreads();
+    if (tid < CB) {
+      for (int j = 1; j < nl; ++j) { sa += red[(j * CB + tid) * 2]; sq += red[(j * CB + tid) * 2 + 1]; }
+      const double n = (double)HW;
+      cs[tid * 2] = sa / n; cs[tid * 2 + 1] = sq - sa * sa / n;
+    }
+    __syncthreads();
+  }
+  if (tid < CB / cpg) {
+    double m = 0;
+    for (int q = tid * cpg; q < (tid + 1) * cpg; ++q) m += cs[q * 2];
+    m /= cpg;
+    double M2 = 0;
+    for (int q = tid * cpg; q < (tid + 1) * cpg; ++q) { const double d = cs[q * 2] - m; M2 += cs[q * 2 + 1] + (double)HW * d * d; }
+    double var = M2 / ((double)cpg * (double)HW); if (var < 0) var = 0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)a.eps));
+    gs[tid * 2] = (float)m; gs[tid * 2 + 1] = rstd;
+    const int g = c0 / cpg + tid;
+    a.stat[((long)b * G + g) * 2] = (float)m; a.stat[((long)b * G + g) * 2 + 1] = rstd;
+  }
+  __syncthreads();
+  if (tid < CB) {
+    const int c = c0 + tid, gl = tid / cpg;
+    const float rstd = gs[gl * 2 + 1];
+    const float sc = a.scale ? a.scale[c] : 0.f, t = a.shift ? a.shift[c] : 0.f;
+    float4 o4; o4.x = rstd * a.gamma[c] * (1.f + sc); o4.y = a.beta[c] * (1.f + sc) + t; o4.z = gs[gl * 2]; o4.w = rstd;
+    reinterpret_cast<float4*>(a.coef)[(long)b * C + c] = o4;
+    cof[tid * 3] = o4.x; cof[tid * 3 + 1] = o4.y; cof[tid * 3 + 2] = o4.z;
+  }
+  __syncthreads();
+  // ---- apply (gn_apply_kernel<T, RS_NONE> restricted to the bundle's channels)
+  const int CVb = CB / VEC, PL = 256 / CVb, cv = tid % CVb, pl = tid / CVb;
+  if (pl >= PL) return;
+  float A[VEC], Bc[VEC], mu[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) { A[e] = cof[(cv * VEC + e) * 3]; Bc[e] = cof[(cv * VEC + e) * 3 + 1]; mu[e] = cof[(cv * VEC + e) * 3 + 2]; }
+  const T* xp = reinterpret_cast<const T*>(a.x.p) + (long)b * HW * a.x.ld + c0 + cv * VEC;
+  T* yp = reinterpret_cast<T*>(a.y.p) + (long)b * HW * a.y.ld + c0 + cv * VEC;
+  const float keep = 1.f - a.drop_p, inv_keep = a.drop_p > 0.f ? 1.f / keep : 1.f;
+  const uint32_t dkey = drop_key(a.drop_seed, a.drop_stream), dthr = drop_thr16(keep);
+  constexpr int U = 4;
+  for (long p = pl; p < HW; p += (long)PL * U) {
+    V16 rx[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) { const long pp = p + (long)u * PL; rx[u] = ldv<T>(xp + (pp < HW ? pp : p) * a.x.ld); }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long pp = p + (long)u * PL;
+      if (pp < HW) {
+        float v[VEC], o[VEC];
+        unpack<T>(rx[u], v);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) o[e] = silu_f<false>(A[e] * (v[e] - mu[e]) + Bc[e]);
+        if (a.drop_p > 0.f) {
+          const uint64_t base = ((uint64_t)(b + a.b0) * HW + pp) * (uint64_t)C + (uint64_t)(c0 + cv * VEC);
+          const uint32_t kb = drop_keep_bits<VEC>(a, dkey, dthr, base);
+          if (a.keep_bits) a.keep_bits[base >> 3] = (uint8_t)kb;
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) o[e] = ((kb >> e) & 1u) ? o[e] * inv_keep : 0.f;
+        }
+        stv<T>(yp + pp * a.y.ld, pack<T>(o));
+      }
+    }
+  }
+}
+
 // the apply kernel alone (statistics / coefficients already in place); also the unit timed by pu_bench_gn
 template <typename T>
 hipError_t launch_gn_apply(const GNArgs& a, hipStream_t s) {
@@ -389,6 +490,14 @@ hipError_t launch_gn_fwd(const GNArgs& a0, hipStream_t s) {
     const int nb = min(step, a0.x.B - b0);
     const GNArgs a = gn_sub(a0, b0, nb, sizeof(T));
     const bool fused = a.ps0 && a.ns0 > 0 && (a.pc0 >= a.x.C || (a.ps1 && a.ns1 > 0)) && step == a0.x.B;
+    if constexpr (sizeof(T) == 2) {
+      static const bool no_small = getenv("PU_NO_GN_SMALL_FWD") != nullptr;      // diagnostic: finalize + apply for every tensor
+      const int cb = gn_bundle_channels(a.x.C, a.G);
+      if (fused && !no_small && a.resample == RS_NONE && (long)a.x.H * a.x.W <= 1024 && cb > 0 && 256 % cb == 0 && (a.pc0 >= a.x.C || a.pc0 % cb == 0)) {
+        hipLaunchKernelGGL(gn_small_fwd_kernel<T>, dim3(a.x.C / cb, a.x.B), dim3(256), 0, s, a, cb);
+        continue;
+      }
+    }
     if (!fused) hipLaunchKernelGGL((chan_partial_kernel<T, true>), dim3(a.nchunk, a.x.B), dim3(256), 0, s, a.x, a.part, a.nchunk, 1);
     hipLaunchKernelGGL((gn_finalize_kernel<T, 1024>), dim3(a.x.B), dim3(1024), 0, s, a.x, a.part, a.nchunk, a.G, a.eps, a.gamma, a.beta,
                        a.scale, a.shift, a.stat, a.coef, fused ? a.ps0 : nullptr, a.ns0, a.pc0, a.ps1, a.ns1);
