@@ -323,16 +323,22 @@ __global__ __launch_bounds__(256) void fcomb_fwd16_kernel(FcombArgs f, const flo
   for (int r = 0; r < 16; ++r) { b1r[r] = f.b1[fc_row(r, h)]; b2r[r] = fc_row(r, h) < f.Cout ? f.b2[fc_row(r, h)] : 0.f; }
   __syncthreads();
   const long ntile = (HW + 31) / 32;
+  // the feature rows of the wave's NEXT tile are fetched while the members of the current one are processed (unconditional loads from a
+  // clamped pixel: rows beyond the image are never stored); the load used to sit in front of the first MFMA of every tile
+  V16 nxf[2];
+  auto load_feat = [&](long t, V16* o) __attribute__((always_inline)) {
+    long px = t * 32 + j; if (px >= HW) px = HW - 1;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) o[s] = *reinterpret_cast<const V16*>(fp + px * f.feat.ld + 16 * s + 8 * h);
+  };
+  load_feat((long)blockIdx.x * 4 + wave, nxf);
   for (long t = (long)blockIdx.x * 4 + wave; t < ntile; t += (long)gridDim.x * 4) {
     const long pix = t * 32 + j;
     const bool valid = pix < HW;
     typename M::Frag fb[2];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      union { V16 v; typename M::Frag fr; } u; u.v = zero16();
-      if (valid) u.v = *reinterpret_cast<const V16*>(fp + pix * f.feat.ld + 16 * s + 8 * h);
-      fb[s] = u.fr;
-    }
+    for (int s = 0; s < 2; ++s) { union { V16 v; typename M::Frag fr; } u; u.v = nxf[s]; fb[s] = u.fr; }
+    load_feat(t + (long)gridDim.x * 4, nxf);
     // the W0f . feat product is shared by all members: keep it, add the member's z-bias afterwards
     f32x16 pre;
 #pragma unroll
