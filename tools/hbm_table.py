@@ -9,14 +9,21 @@ stats = list(csv.DictReader(open(os.path.join(R, "profiles", f"{tag}_final_bench
 sq = {r["kernel"]: r for r in json.load(open(os.path.join(R, "profiles", f"{tag}_pmc_sq_mfma.json")))}
 
 def short(n):
-    """the tag tools/pmc_summary.py gives the same kernel: _ZN2pu12conv3_kernelIDF16_Li3E...E -> conv3_kernel<f16,3,...>; others verbatim"""
-    m = re.match(r"_ZN2pu\d+([a-z0-9_]+)I(DF16_|NS_4bf16E|f)((?:Li\d+E)*)", n)
-    if not m:
-        return n
+    """kernel tag: conv3* as bench.py prints them, other kernels with every template argument"""
+    m = re.match(r"_ZN2pu\d+([a-z0-9_]+)I(DF16_|NS_4bf16E|f)((?:L[ib]\d+E)*)", n)
+    if not m: return n
     dt = {"DF16_": "f16", "NS_4bf16E": "bf16", "f": "f32"}[m.group(2)]
-    nums = re.findall(r"Li(\d+)E", m.group(3))
-    return m.group(1) + "<" + ",".join([dt] + nums) + ">"
-
+    toks = re.findall(r"L([ib])(\d+)E", m.group(3))
+    if m.group(1).startswith("conv3"):          # bench.py's profiling tags: integers up to the bool, ",1" for the GroupNorm-backward epilogue
+        nums = []
+        for kind, v in toks:
+            if kind == "b":
+                if v == "1": nums.append("1")
+                break
+            nums.append(v)
+    else:
+        nums = [v for _, v in toks]             # every template argument (several instantiations of one GroupNorm kernel stay apart)
+    return f"{m.group(1)}<{','.join([dt] + nums)}>"
 dom = next(int(r["Calls"]) for r in stats if "conv3_kernel" in r["Name"] and "Li3ELi4ELi32ELi1ELi4ELi16" in r["Name"])
 steps = dom / 80.0
 rows = []
@@ -34,4 +41,6 @@ print(f"{'kernel':58s} {'ms/step':>8s} {'n/step':>7s} {'us':>8s} {'MB':>8s} {'TB
 for ms, k, n, us, mb, tbs, mf in rows:
     if ms < 0.02:
         continue
-    print(f"{k[:58]:58s} {ms:8.3f} {n:7.1f} {us:8.1f} {mb:8.1f} {tbs:6.2f} {tbs / 8:5.2f} {('%.2f' % mf) if mf is not None else '   -'}")
+    # rows above ~6.5 TB/s are not evidence of HBM rate: the blanket FETCH_SIZE x 2 correction over-counts narrow / Infinity-Cache-resident reads
+    note = "  (> 6.5 TB/s: counter correction over-applies, not evidence)" if tbs > 6.5 else ""
+    print(f"{k[:58]:58s} {ms:8.3f} {n:7.1f} {us:8.1f} {mb:8.1f} {tbs:6.2f} {tbs / 8:5.2f} {('%.2f' % mf) if mf is not None else '   -'}{note}")

@@ -9,15 +9,21 @@ def agg(path):
     return acc
 
 def tag(mangled):
-    """_ZN2pu12conv3_kernelIDF16_Li3ELi8ELi32ELi1ELi4ELi16ELb0EEEvNS_8ConvArgsE -> conv3_kernel<f16,3,8,32,1,4,16> (bench.py's tag); a true
-    bool argument (the GroupNorm-backward epilogue instantiation, Lb1E) appends ",1" as the launcher's profiling tag does, template
-    arguments after the bool (conv3p's prefetch depth) are not part of the tag"""
-    m = re.match(r"_ZN2pu\d+([a-z0-9_]+)I(DF16_|NS_4bf16E|f)((?:Li\d+E)*)((?:Lb[01]E)?)", mangled)
+    """kernel tag: conv3* as bench.py prints them, other kernels with every template argument"""
+    m = re.match(r"_ZN2pu\d+([a-z0-9_]+)I(DF16_|NS_4bf16E|f)((?:L[ib]\d+E)*)", mangled)
     if not m: return mangled
     dt = {"DF16_": "f16", "NS_4bf16E": "bf16", "f": "f32"}[m.group(2)]
-    nums = re.findall(r"Li(\d+)E", m.group(3))
-    return f"{m.group(1)}<{','.join([dt] + nums + (['1'] if m.group(4) == 'Lb1E' else []))}>"
-
+    toks = re.findall(r"L([ib])(\d+)E", m.group(3))
+    if m.group(1).startswith("conv3"):          # bench.py's profiling tags: integers up to the bool, ",1" for the GroupNorm-backward epilogue
+        nums = []
+        for kind, v in toks:
+            if kind == "b":
+                if v == "1": nums.append("1")
+                break
+            nums.append(v)
+    else:
+        nums = [v for _, v in toks]             # every template argument (several instantiations of one GroupNorm kernel stay apart)
+    return f"{m.group(1)}<{','.join([dt] + nums)}>"
 f, w = agg(sys.argv[1]), agg(sys.argv[2])
 out = {}
 for k in f:
